@@ -1,0 +1,152 @@
+/*
+ * spatialcore_hip.h -- C ABI of libspatialcore_hip.so (MI355X / gfx950).
+ *
+ * The reference (mcap91/SpatialCore, /root/reference) is pure Python: it has no FFI of its own.
+ * The drop-in boundary is the Python surface of `spatialcore.spatial`
+ * (reference src/spatialcore/spatial/__init__.py:11-52); spatialcore_amd/spatial/ mirrors those
+ * functions and reaches the GPU only through the entry points declared here (ctypes).
+ * Each entry point names the reference call site(s) whose arithmetic it replaces;
+ * AC = src/spatialcore/spatial/autocorrelation.py, NB = src/spatialcore/spatial/neighborhoods.py.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns an int status (SC_OK = 0) and never
+ *    throws; sc_last_error() returns the text of the last failure on the calling thread.
+ *  - the caller owns all host buffers; the library owns device memory behind the opaque handle.
+ *  - one handle = one GPU + one HIP stream; a handle is not thread-safe.
+ *  - host arrays are C-contiguous.  "gene-major" means [gene][cell].
+ */
+#ifndef SPATIALCORE_HIP_H
+#define SPATIALCORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_INVALID 1  /* bad argument            -> ValueError in the Python shim */
+#define SC_ERR_STATE 2    /* call order / missing setup -> RuntimeError                */
+#define SC_ERR_HIP 3      /* HIP runtime failure     -> RuntimeError                   */
+#define SC_ERR_NOMEM 4    /* device/host allocation  -> MemoryError                    */
+#define SC_ERR_EMPTY 5    /* empty neighbourhoods (NB:253-260) -> ValueError           */
+
+/* expression value types accepted by sc_expr_* */
+#define SC_F32 0
+#define SC_F64 1
+
+/* kernel ids for sc_ctx_kernel_time */
+#define SC_K_MORAN_PERM 0 /* gather-dot permutation kernel (the metric's dominant kernel) */
+#define SC_K_LAG 1
+#define SC_K_KNN 2
+#define SC_K_PERMGEN 3
+#define SC_K_LEE_PERM 4
+#define SC_K_COUNT_ 8
+
+typedef struct sc_ctx sc_ctx;
+
+int sc_version(void);
+const char *sc_last_error(void);
+int sc_device_count(int *count);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int sc_ctx_create(int device, sc_ctx **out);
+int sc_ctx_destroy(sc_ctx *ctx);
+int sc_ctx_sync(sc_ctx *ctx);
+/* Accumulated HIP-event time (ms) and launch count of one kernel family since the last reset. */
+int sc_ctx_kernel_time(sc_ctx *ctx, int kernel_id, double *ms, int64_t *launches);
+int sc_ctx_reset_timers(sc_ctx *ctx);
+/* Enable/disable per-launch HIP-event timing (default on; events are recorded on the ctx stream). */
+int sc_ctx_set_timing(sc_ctx *ctx, int enabled);
+int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
+
+/* ---- A1: kNN graph ------------------------------------------------------------------------
+ * Replaces sklearn NearestNeighbors(k+1, "ball_tree").kneighbors + "drop column 0" (AC:393-401),
+ * squidpy's NearestNeighbors(k).kneighbors() behind sq.gr.spatial_neighbors (AC:565-570) and
+ * scipy cKDTree.query(k+1) + "drop == i" (NB:213-228).
+ * xy: [n][2] float64.  idx_out: [n][k] int32, neighbours ordered by (squared distance, index);
+ * squared distance = fl(fl(dx*dx) + fl(dy*dy)) in fp64 (no FMA contraction), as the tree codes
+ * compute it.  Self is excluded BY INDEX unless include_self (then k counts self, AC:398).
+ * rdist_out (nullable): [n][k] squared distances.  The result also stays on the device and can be
+ * turned into the active graph with sc_graph_from_knn. */
+int sc_knn_2d(sc_ctx *ctx, const double *xy, int64_t n, int k, int include_self,
+              int32_t *idx_out, double *rdist_out);
+
+/* ---- A2: radius graph ---------------------------------------------------------------------
+ * Replaces cKDTree.query_ball_point(coords, r) with self removed (NB:241-244): closed ball
+ * fl(dx*dx+dy*dy) <= fl(r*r).  Two-pass: count fills indptr_out[n+1]; fill writes nnz indices,
+ * ascending within each row.  The coordinates of the count call stay resident for the fill call. */
+int sc_radius_count_2d(sc_ctx *ctx, const double *xy, int64_t n, double radius, int64_t *indptr_out);
+int sc_radius_fill_2d(sc_ctx *ctx, int64_t nnz, int32_t *indices_out);
+
+/* ---- A3: graph / weights ------------------------------------------------------------------
+ * The active graph is a general CSR with fp64 weights (user graphs from use_existing_graph,
+ * AC:558-561, are general).  sc_graph_from_knn builds it on the device from the last sc_knn_2d
+ * result with w = weight for every edge and rows sorted by column index, i.e. the matrix that
+ * AC:402-413 (weight = (double)(float)(1/k)) or squidpy + l1 row normalisation (weight = 1.0/k)
+ * produce.  sc_graph_get copies the device CSR back (indices ascending per row). */
+int sc_graph_set_csr(sc_ctx *ctx, const int64_t *indptr, const int32_t *indices, const double *data,
+                     int64_t n, int64_t nnz);
+int sc_graph_from_knn(sc_ctx *ctx, double weight);
+int sc_graph_get(sc_ctx *ctx, int64_t *indptr_out, int32_t *indices_out, double *data_out);
+int sc_graph_shape(sc_ctx *ctx, int64_t *n, int64_t *nnz);
+/* A6 [upstream squidpy _g_moments]: s0 = sum w, s1 = 1/2 sum (w_ij + w_ji)^2, s2 = sum_i (row_i + col_i)^2 */
+int sc_graph_moments(sc_ctx *ctx, double *s0, double *s1, double *s2);
+
+/* ---- expression operands ------------------------------------------------------------------
+ * Select n_genes columns of a cells x n_vars matrix and lay them out on the device as 16-gene
+ * tiles [tile][cell][16] fp64 (one 128-byte row per cell and tile).  Replaces
+ * `adata[:, genes]` + densify + cast (AC:573 then scanpy's float64 cast; AC:1118-1123).
+ * CSR: indptr int64[n+1], indices int32[nnz], data f32/f64.  Dense: row-major, ld = n_vars. */
+int sc_expr_set_csr(sc_ctx *ctx, const int64_t *indptr, const int32_t *indices, const void *data,
+                    int dtype, int64_t n, int64_t n_vars, const int32_t *gene_cols, int64_t n_genes);
+int sc_expr_set_dense(sc_ctx *ctx, const void *data, int dtype, int64_t n, int64_t n_vars,
+                      const int32_t *gene_cols, int64_t n_genes);
+/* per-gene mean and population variance of the loaded columns (fp64) */
+int sc_expr_stats(sc_ctx *ctx, double *mean_out, double *var_out);
+
+/* ---- A4: permutation source ---------------------------------------------------------------
+ * numpy-exact `rng.permutation(n)` stream (AC:839,879; AC:1109,324; AC:1367,1404; squidpy
+ * _score_helper): state6 = {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger} of a PCG64
+ * Generator, updated in place.  sc_perm_numpy_host fills a host table [n_perm][n] int32 (no GPU);
+ * sc_perm_generate makes the same table resident on the device as the active permutation table
+ * (perm_out nullable: copy back).  sc_perm_set uploads a caller-made table. */
+int sc_perm_numpy_host(uint64_t *state6, int64_t n, int64_t n_perm, int32_t *perm_out);
+int sc_perm_generate(sc_ctx *ctx, uint64_t *state6, int64_t n, int64_t n_perm, int32_t *perm_out);
+int sc_perm_set(sc_ctx *ctx, const int32_t *perm, int64_t n, int64_t n_perm);
+
+/* ---- A3 + A5 + A6 + A7: global Moran's I --------------------------------------------------
+ * Replaces sq.gr.spatial_autocorr(mode="moran", n_perms=P, seed=seed) (AC:576-583):
+ * z = x - mean; lag = W z (row-sequential fp64); I = n/s0 * sum z*lag / sum z^2;
+ * sims[p][g] = n/s0 * sum_i z_g[i] * lag_g[perm_p[i]] / sum z_g^2  (== scoring g[perm_p, :]).
+ * Needs: active graph, expression, and (if n_perm > 0) an active permutation table.
+ * Outputs (host, all nullable except I_out): I_out[G]; sims_out[n_perm][G];
+ * count_ge_out[G] = #{p : sims[p][g] >= I[g]}; sim_sum_out[G], sim_sumsq_out[G] = sum and sum of
+ * squares of sims over p (for squidpy's pval_z_sim / var_sim). */
+int sc_moran(sc_ctx *ctx, int64_t n_perm, double *I_out, double *sims_out, int64_t *count_ge_out,
+             double *sim_sum_out, double *sim_sumsq_out);
+
+/* ---- A8: Lee's L ---------------------------------------------------------------------------
+ * Replaces _compute_lees_l_core (AC:307-332) for a list of (x, y) pairs over the loaded genes.
+ * Standardisation is the population-std z-score of AC:1126-1143.  L = sum_i zx_i * (W zy)_i.
+ * L_perm[p] = sum_j (W^T zx)_j * zy[perm[j]] (== shuffling zy and redoing W @ zy).  Pair q uses
+ * rows [perm_offset[q], perm_offset[q]+n_perm) of the active permutation table (the reference
+ * draws a fresh block of P permutations per non-degenerate pair from ONE stream, AC:1109-1148);
+ * pairs with perm_offset[q] < 0 (zero variance, AC:1129-1140) get L = 0, count = n_perm.
+ * Outputs: L_out[n_pairs], count_abs_ge_out[n_pairs] = #{p : |L_perm| >= |L|}, L_perm_out
+ * (nullable) [n_pairs][n_perm]. */
+int sc_lee(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, const int64_t *perm_offset,
+           int64_t n_pairs, int64_t n_perm, double *L_out, int64_t *count_abs_ge_out,
+           double *L_perm_out);
+
+/* ---- A9: neighbourhood composition --------------------------------------------------------
+ * Replaces the per-cell Python counting loops of NB:226-251 on the active graph's pattern:
+ * counts_out[n][n_types] float32 = number of neighbours of each label.  Rows with no neighbour
+ * give SC_ERR_EMPTY (NB:253-260) and n_empty_out is set. */
+int sc_profile_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types,
+                      float *counts_out, int64_t *n_empty_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPATIALCORE_HIP_H */

@@ -1,0 +1,319 @@
+"""ctypes binding of libspatialcore_hip.so (include/spatialcore_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no gfx950
+device is visible, the first call that needs the GPU raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspatialcore_hip.so")
+
+SC_OK, SC_ERR_INVALID, SC_ERR_STATE, SC_ERR_HIP, SC_ERR_NOMEM, SC_ERR_EMPTY = 0, 1, 2, 3, 4, 5
+SC_F32, SC_F64 = 0, 1
+K_MORAN_PERM, K_LAG, K_KNN, K_PERMGEN, K_LEE_PERM = 0, 1, 2, 3, 4
+
+# every symbol include/spatialcore_hip.h declares: (name, argtypes); restype is always int
+_P = c_void_p
+SYMBOLS = {
+    "sc_version": [],
+    "sc_device_count": [POINTER(c_int)],
+    "sc_ctx_create": [c_int, POINTER(c_void_p)],
+    "sc_ctx_destroy": [_P],
+    "sc_ctx_sync": [_P],
+    "sc_ctx_kernel_time": [_P, c_int, POINTER(c_double), POINTER(c_int64)],
+    "sc_ctx_reset_timers": [_P],
+    "sc_ctx_set_timing": [_P, c_int],
+    "sc_ctx_device_mem": [_P, POINTER(c_int64)],
+    "sc_knn_2d": [_P, _P, c_int64, c_int, c_int, _P, _P],
+    "sc_radius_count_2d": [_P, _P, c_int64, c_double, _P],
+    "sc_radius_fill_2d": [_P, c_int64, _P],
+    "sc_graph_set_csr": [_P, _P, _P, _P, c_int64, c_int64],
+    "sc_graph_from_knn": [_P, c_double],
+    "sc_graph_get": [_P, _P, _P, _P],
+    "sc_graph_shape": [_P, POINTER(c_int64), POINTER(c_int64)],
+    "sc_graph_moments": [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)],
+    "sc_expr_set_csr": [_P, _P, _P, _P, c_int, c_int64, c_int64, _P, c_int64],
+    "sc_expr_set_dense": [_P, _P, c_int, c_int64, c_int64, _P, c_int64],
+    "sc_expr_stats": [_P, _P, _P],
+    "sc_perm_numpy_host": [_P, c_int64, c_int64, _P],
+    "sc_perm_generate": [_P, _P, c_int64, c_int64, _P],
+    "sc_perm_set": [_P, _P, c_int64, c_int64],
+    "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
+    "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
+    "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class SpatialCoreHipError(RuntimeError):
+    """HIP runtime / library-state failure reported by libspatialcore_hip.so."""
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the shared library (no GPU needed for loading).  Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C spatialcore_amd/csrc`.  There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, argtypes in SYMBOLS.items():
+                fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+                fn.argtypes = argtypes
+                fn.restype = c_int
+            lib.sc_last_error.argtypes = []
+            lib.sc_last_error.restype = c_char_p
+            _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc == SC_OK:
+        return
+    msg = load_library().sc_last_error().decode("utf-8", "replace")
+    if rc in (SC_ERR_INVALID, SC_ERR_EMPTY):
+        raise ValueError(msg)
+    if rc == SC_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise SpatialCoreHipError(msg)
+
+
+def device_count() -> int:
+    n = c_int(0)
+    rc = load_library().sc_device_count(byref(n))
+    return n.value if rc == SC_OK else 0
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def rng_state_words(rng: np.random.Generator) -> np.ndarray:
+    """PCG64 Generator state as the 6 uint64 words sc_perm_* take.  The seed -> state expansion
+    (SeedSequence) stays in numpy; only the stream itself is re-implemented natively."""
+    st = rng.bit_generator.state
+    if st.get("bit_generator") != "PCG64":
+        raise ValueError("only numpy PCG64 generators (np.random.default_rng) are supported")
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = 0xFFFFFFFFFFFFFFFF
+    return np.array([s >> 64, s & m, inc >> 64, inc & m, st["has_uint32"], st["uinteger"]], dtype=np.uint64)
+
+
+def set_rng_state(rng: np.random.Generator, words: np.ndarray) -> None:
+    w = [int(x) for x in words]
+    rng.bit_generator.state = {"bit_generator": "PCG64",
+                               "state": {"state": (w[0] << 64) | w[1], "inc": (w[2] << 64) | w[3]},
+                               "has_uint32": w[4], "uinteger": w[5]}
+
+
+def perm_numpy_host(words: np.ndarray, n: int, n_perm: int) -> np.ndarray:
+    """Host-only numpy-exact permutation table (no GPU needed).  `words` is updated in place."""
+    out = np.empty((n_perm, n), dtype=np.int32)
+    _check(load_library().sc_perm_numpy_host(_ptr(words), n, n_perm, _ptr(out)))
+    return out
+
+
+class Context:
+    """One GPU + one HIP stream + the device-resident operands of the hot path."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = c_void_p()
+        _check(self._lib.sc_ctx_create(int(device), byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.sc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def sync(self) -> None:
+        _check(self._lib.sc_ctx_sync(self._h))
+
+    def kernel_time(self, kernel_id: int) -> Tuple[float, int]:
+        ms, cnt = c_double(0), c_int64(0)
+        _check(self._lib.sc_ctx_kernel_time(self._h, kernel_id, byref(ms), byref(cnt)))
+        return ms.value, cnt.value
+
+    def reset_timers(self) -> None:
+        _check(self._lib.sc_ctx_reset_timers(self._h))
+
+    def set_timing(self, enabled: bool) -> None:
+        _check(self._lib.sc_ctx_set_timing(self._h, int(enabled)))
+
+    def device_mem(self) -> int:
+        v = c_int64(0)
+        _check(self._lib.sc_ctx_device_mem(self._h, byref(v)))
+        return v.value
+
+    # ---- A1 / A2 ----------------------------------------------------------------------------
+    def knn(self, coords, k: int, include_self: bool = False, return_distance: bool = False,
+            fetch: bool = True):
+        xy = _c(coords, np.float64)
+        if xy.ndim != 2 or xy.shape[1] != 2:
+            raise ValueError(f"coordinates must have shape (n, 2), got {xy.shape}")
+        n = xy.shape[0]
+        idx = np.empty((n, k), dtype=np.int32) if fetch else None
+        rd = np.empty((n, k), dtype=np.float64) if (return_distance and fetch) else None
+        _check(self._lib.sc_knn_2d(self._h, _ptr(xy), n, int(k), int(include_self), _ptr(idx), _ptr(rd)))
+        return (idx, rd) if return_distance else idx
+
+    def radius_graph(self, coords, radius: float):
+        xy = _c(coords, np.float64)
+        if xy.ndim != 2 or xy.shape[1] != 2:
+            raise ValueError(f"coordinates must have shape (n, 2), got {xy.shape}")
+        n = xy.shape[0]
+        indptr = np.empty(n + 1, dtype=np.int64)
+        _check(self._lib.sc_radius_count_2d(self._h, _ptr(xy), n, float(radius), _ptr(indptr)))
+        nnz = int(indptr[-1])
+        indices = np.empty(nnz, dtype=np.int32)
+        _check(self._lib.sc_radius_fill_2d(self._h, nnz, _ptr(indices)))
+        return indptr, indices
+
+    # ---- A3 ---------------------------------------------------------------------------------
+    def set_graph_csr(self, indptr, indices, data, n: int) -> None:
+        indptr = _c(indptr, np.int64)
+        indices = _c(indices, np.int32)
+        data = _c(data, np.float64)
+        _check(self._lib.sc_graph_set_csr(self._h, _ptr(indptr), _ptr(indices), _ptr(data), int(n), int(indices.size)))
+
+    def graph_from_knn(self, weight: float) -> None:
+        _check(self._lib.sc_graph_from_knn(self._h, float(weight)))
+
+    def graph_shape(self) -> Tuple[int, int]:
+        n, nnz = c_int64(0), c_int64(0)
+        _check(self._lib.sc_graph_shape(self._h, byref(n), byref(nnz)))
+        return n.value, nnz.value
+
+    def get_graph(self):
+        n, nnz = self.graph_shape()
+        indptr = np.empty(n + 1, dtype=np.int64)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz, dtype=np.float64)
+        _check(self._lib.sc_graph_get(self._h, _ptr(indptr), _ptr(indices), _ptr(data)))
+        return indptr, indices, data
+
+    def graph_moments(self) -> Tuple[float, float, float]:
+        a, b, d = c_double(0), c_double(0), c_double(0)
+        _check(self._lib.sc_graph_moments(self._h, byref(a), byref(b), byref(d)))
+        return a.value, b.value, d.value
+
+    # ---- expression -------------------------------------------------------------------------
+    def set_expression(self, X, gene_cols) -> None:
+        """X: scipy sparse (any format) or dense (cells x n_vars); gene_cols: distinct column ids."""
+        from scipy import sparse
+
+        cols = _c(gene_cols, np.int32)
+        if sparse.issparse(X):
+            Xc = X.tocsr()
+            if not Xc.has_canonical_format:
+                Xc = Xc.copy()
+                Xc.sum_duplicates()
+            dt = SC_F32 if Xc.dtype == np.float32 else SC_F64
+            data = _c(Xc.data, np.float32 if dt == SC_F32 else np.float64)
+            indptr = _c(Xc.indptr, np.int64)
+            indices = _c(Xc.indices, np.int32)
+            _check(self._lib.sc_expr_set_csr(self._h, _ptr(indptr), _ptr(indices), _ptr(data), dt, Xc.shape[0],
+                                             Xc.shape[1], _ptr(cols), cols.size))
+        else:
+            A = np.asarray(X)
+            if A.ndim != 2:
+                raise ValueError("expression matrix must be 2-D")
+            # ship only the requested columns when they are a small part of a wide matrix
+            if A.shape[1] > 2 * cols.size:
+                A = A[:, cols]
+                cols = np.arange(cols.size, dtype=np.int32)
+            dt = SC_F32 if A.dtype == np.float32 else SC_F64
+            A = _c(A, np.float32 if dt == SC_F32 else np.float64)
+            _check(self._lib.sc_expr_set_dense(self._h, _ptr(A), dt, A.shape[0], A.shape[1], _ptr(cols), cols.size))
+        self._n_genes = int(cols.size)
+
+    def expr_stats(self):
+        mean = np.empty(self._n_genes, dtype=np.float64)
+        var = np.empty(self._n_genes, dtype=np.float64)
+        _check(self._lib.sc_expr_stats(self._h, _ptr(mean), _ptr(var)))
+        return mean, var
+
+    # ---- A4 ---------------------------------------------------------------------------------
+    def generate_permutations(self, words: np.ndarray, n: int, n_perm: int, fetch: bool = False):
+        out = np.empty((n_perm, n), dtype=np.int32) if fetch else None
+        _check(self._lib.sc_perm_generate(self._h, _ptr(words), int(n), int(n_perm), _ptr(out)))
+        return out
+
+    def set_permutations(self, perm) -> None:
+        perm = _c(perm, np.int32)
+        if perm.ndim != 2:
+            raise ValueError("permutation table must have shape (n_perm, n)")
+        _check(self._lib.sc_perm_set(self._h, _ptr(perm), perm.shape[1], perm.shape[0]))
+
+    # ---- A5-A8 ------------------------------------------------------------------------------
+    def moran(self, n_perm: int, return_sims: bool = True):
+        G = self._n_genes
+        I = np.empty(G, dtype=np.float64)
+        sims = np.empty((n_perm, G), dtype=np.float64) if (n_perm > 0 and return_sims) else None
+        cnt = np.zeros(G, dtype=np.int64) if n_perm > 0 else None
+        ssum = np.zeros(G, dtype=np.float64) if n_perm > 0 else None
+        ssq = np.zeros(G, dtype=np.float64) if n_perm > 0 else None
+        _check(self._lib.sc_moran(self._h, int(n_perm), _ptr(I), _ptr(sims), _ptr(cnt), _ptr(ssum), _ptr(ssq)))
+        return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
+
+    def lee(self, pair_x, pair_y, perm_offset, n_perm: int, return_perms: bool = False):
+        px, py = _c(pair_x, np.int32), _c(pair_y, np.int32)
+        off = _c(perm_offset, np.int64) if perm_offset is not None else None
+        q = px.size
+        L = np.empty(q, dtype=np.float64)
+        cnt = np.zeros(q, dtype=np.int64)
+        Lp = np.empty((q, n_perm), dtype=np.float64) if return_perms else None
+        _check(self._lib.sc_lee(self._h, _ptr(px), _ptr(py), _ptr(off), q, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
+        return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
+
+    # ---- A9 ---------------------------------------------------------------------------------
+    def profile_counts(self, labels, n_types: int) -> np.ndarray:
+        lab = _c(labels, np.int32)
+        out = np.empty((lab.size, n_types), dtype=np.float32)
+        empty = c_int64(0)
+        _check(self._lib.sc_profile_counts(self._h, _ptr(lab), lab.size, int(n_types), _ptr(out), byref(empty)))
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    """Process-wide context per device (created on first use; raises without a gfx950 GPU)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,209 @@
+// Context, error and timer plumbing of libspatialcore_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "sc_ctx.h"
+
+static thread_local char g_err[1024] = "";
+
+void sc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DBuf::ensure(size_t bytes, int64_t *acct)
+{
+    if (bytes <= cap) return SC_OK;
+    if (p) {
+        (void)hipFree(p);
+        *acct -= (int64_t)cap;
+        p = nullptr;
+        cap = 0;
+    }
+    // round up so that small growth does not re-allocate
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        sc_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_HIP;
+    }
+    cap = want;
+    *acct += (int64_t)cap;
+    return SC_OK;
+}
+
+void DBuf::release(int64_t *acct)
+{
+    if (p) {
+        (void)hipFree(p);
+        *acct -= (int64_t)cap;
+    }
+    p = nullptr;
+    cap = 0;
+}
+
+KernelTimerScope::KernelTimerScope(sc_ctx *ctx, int kid) : c(ctx), id(kid)
+{
+    if (!c->timing) return;
+    KTimer &t = c->timers[id];
+    if (!t.pool.empty()) {
+        a = t.pool.back().first;
+        b = t.pool.back().second;
+        t.pool.pop_back();
+    } else {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            a = b = nullptr;
+            return;
+        }
+    }
+    (void)hipEventRecord(a, c->stream);
+}
+
+KernelTimerScope::~KernelTimerScope()
+{
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    KTimer &t = c->timers[id];
+    t.pending.emplace_back(a, b);
+    t.launches += 1;
+}
+
+int sc_timer_collect(sc_ctx *c)
+{
+    SC_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < SC_K_COUNT_; ++k) {
+        KTimer &t = c->timers[k];
+        for (auto &ev : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t.ms += ms;
+            t.pool.push_back(ev);
+        }
+        t.pending.clear();
+    }
+    return SC_OK;
+}
+
+extern "C" {
+
+int sc_version(void) { return 100; }
+
+const char *sc_last_error(void) { return g_err; }
+
+int sc_device_count(int *count)
+{
+    SC_REQUIRE(count, SC_ERR_INVALID, "sc_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        sc_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return SC_ERR_HIP;
+    }
+    *count = n;
+    return SC_OK;
+}
+
+int sc_ctx_create(int device, sc_ctx **out)
+{
+    SC_REQUIRE(out, SC_ERR_INVALID, "sc_ctx_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    SC_HIP(hipGetDeviceCount(&n));
+    SC_REQUIRE(device >= 0 && device < n, SC_ERR_INVALID,
+               "sc_ctx_create: device %d out of range (%d visible)", device, n);
+    SC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SC_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        sc_set_error("sc_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                     prop.gcnArchName);
+        return SC_ERR_STATE;
+    }
+    sc_ctx *c = new sc_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        sc_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        return SC_ERR_HIP;
+    }
+    *out = c;
+    return SC_OK;
+}
+
+int sc_ctx_destroy(sc_ctx *c)
+{
+    if (!c) return SC_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,
+                    &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->rad_indptr,
+                    &c->g_indptr, &c->g_indices, &c->g_data, &c->gt_indptr, &c->gt_indices,
+                    &c->gt_data, &c->gt_cursor, &c->X, &c->Z, &c->Lag, &c->e_tmp_indptr,
+                    &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
+                    &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
+                    &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
+                    &c->lee_b, &c->lee_out, &c->lee_pairs};
+    for (DBuf *b : bufs) b->release(&c->mem);
+    for (int k = 0; k < SC_K_COUNT_; ++k) {
+        for (auto &ev : c->timers[k].pending) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        for (auto &ev : c->timers[k].pool) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SC_OK;
+}
+
+int sc_ctx_sync(sc_ctx *c)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+int sc_ctx_kernel_time(sc_ctx *c, int kernel_id, double *ms, int64_t *launches)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_REQUIRE(kernel_id >= 0 && kernel_id < SC_K_COUNT_, SC_ERR_INVALID, "bad kernel id %d", kernel_id);
+    SC_TRY(sc_timer_collect(c));
+    if (ms) *ms = c->timers[kernel_id].ms;
+    if (launches) *launches = c->timers[kernel_id].launches;
+    return SC_OK;
+}
+
+int sc_ctx_reset_timers(sc_ctx *c)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_TRY(sc_timer_collect(c));
+    for (int k = 0; k < SC_K_COUNT_; ++k) {
+        c->timers[k].ms = 0.0;
+        c->timers[k].launches = 0;
+    }
+    return SC_OK;
+}
+
+int sc_ctx_set_timing(sc_ctx *c, int enabled)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    c->timing = enabled != 0;
+    return SC_OK;
+}
+
+int sc_ctx_device_mem(sc_ctx *c, int64_t *bytes)
+{
+    SC_REQUIRE(c && bytes, SC_ERR_INVALID, "null pointer");
+    *bytes = c->mem;
+    return SC_OK;
+}
+
+}  // extern "C"

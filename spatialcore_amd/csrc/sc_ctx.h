@@ -1,0 +1,120 @@
+// Internal definitions shared by the translation units of libspatialcore_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/spatialcore_hip.h"
+
+#define SC_TILE 16  // genes per tile: one 128-byte fp64 row per cell and tile
+
+void sc_set_error(const char *fmt, ...);
+
+#define SC_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            sc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                         __LINE__);                                                          \
+            return e__ == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_HIP;                   \
+        }                                                                                    \
+    } while (0)
+
+#define SC_TRY(call)              \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__ != SC_OK) return rc__; \
+    } while (0)
+
+#define SC_REQUIRE(cond, code, ...)    \
+    do {                               \
+        if (!(cond)) {                 \
+            sc_set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+// Device buffer that only ever grows; freed with the context.
+struct DBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes, int64_t *acct);
+    void release(int64_t *acct);
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct sc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t mem = 0;  // bytes allocated through DBuf
+    bool timing = true;
+    KTimer timers[SC_K_COUNT_];
+
+    // ---- points (kNN / radius) ----
+    int64_t pts_n = 0;
+    DBuf px, py;        // SoA coordinates in original order
+    DBuf sx, sy, sid;   // coordinates / original ids sorted by bin
+    DBuf bin_start;     // [nbins + 1]
+    DBuf bin_keys, bin_keys2, sid2, cub_tmp;
+    int nbx = 0, nby = 0;
+    double gx0 = 0, gy0 = 0, gh = 0;
+    int64_t knn_n = 0;
+    int knn_k = 0;
+    DBuf knn_idx, knn_rd;  // [n][k] device result of the last sc_knn_2d
+    double radius = -1.0;
+    DBuf rad_indptr;  // [n+1] int64 of the last radius count
+
+    // ---- graph (CSR, rows sorted by column) + transpose ----
+    int64_t g_n = 0, g_nnz = 0;
+    DBuf g_indptr, g_indices, g_data;
+    bool gt_valid = false;
+    DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
+    bool s0_valid = false;
+    double s0 = 0.0;
+
+    // ---- expression tiles ----
+    int64_t e_n = 0, e_genes = 0, e_tiles = 0;
+    DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
+    DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
+    DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene
+
+    // ---- permutation table ----
+    int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)
+    DBuf perm;
+    DBuf perm_flag;
+
+    // ---- Moran / Lee work buffers ----
+    DBuf partial, sims, counts, sim_sum, sim_sumsq;
+    DBuf lee_a, lee_b, lee_out, lee_pairs;
+};
+
+struct KernelTimerScope {
+    sc_ctx *c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimerScope(sc_ctx *ctx, int kid);
+    ~KernelTimerScope();
+};
+
+int sc_timer_collect(sc_ctx *c);
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }
+
+// ---- implemented across translation units ----
+int sc_graph_ensure_transpose(sc_ctx *c);
+int sc_graph_ensure_s0(sc_ctx *c);
+int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm);
+void sc_launch_spmv_vec(sc_ctx *c, const int64_t *indptr, const int32_t *indices, const double *w,
+                        const double *x, double *y, int64_t n);

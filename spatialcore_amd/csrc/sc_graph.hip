@@ -1,0 +1,739 @@
+// Neighbour graphs over 2-D coordinates (exact kNN / radius on a uniform bin grid), CSR graph
+// management, squidpy's graph moments, transpose, neighbourhood composition.  gfx950 only.
+//
+// kNN design: points are counting-sorted into square bins (SoA x[], y[], id[] in bin order, so a
+// row of bins is one contiguous, coalesced range).  One thread owns one query and walks square
+// rings of bins around it, keeping its k best (distance, index) pairs in registers (fully unrolled
+// insertion network, no scratch memory).  It stops as soon as the k-th best distance is provably
+// smaller than the distance to anything outside the visited window, so the result is the exact
+// kNN set, ordered by (squared distance, index).  Consecutive threads are consecutive points of the
+// same bin, so a wavefront reads the same candidate ranges (L1 broadcast).
+#include <float.h>
+#include <math.h>
+
+#include <hipcub/hipcub.hpp>
+#include <vector>
+
+#include "sc_ctx.h"
+
+// ------------------------------------------------------------------------------------------------
+// binning
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_split_xy(const double *__restrict__ xy, double *__restrict__ x,
+                                                  double *__restrict__ y, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double2 v = reinterpret_cast<const double2 *>(xy)[i];
+    x[i] = v.x;
+    y[i] = v.y;
+}
+
+__device__ __forceinline__ int bin_coord(double v, double v0, double inv_h, int nb)
+{
+    int b = (int)floor((v - v0) * inv_h);
+    return b < 0 ? 0 : (b >= nb ? nb - 1 : b);
+}
+
+__global__ __launch_bounds__(256) void k_bin_keys(const double *__restrict__ x, const double *__restrict__ y,
+                                                  int64_t n, double x0, double y0, double inv_h, int nbx, int nby,
+                                                  uint32_t *__restrict__ keys, int32_t *__restrict__ ids)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bx = bin_coord(x[i], x0, inv_h, nbx), by = bin_coord(y[i], y0, inv_h, nby);
+    keys[i] = (uint32_t)by * (uint32_t)nbx + (uint32_t)bx;
+    ids[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_gather_sorted(const double *__restrict__ x, const double *__restrict__ y,
+                                                       const int32_t *__restrict__ sid, int64_t n,
+                                                       double *__restrict__ sx, double *__restrict__ sy)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t j = sid[i];
+    sx[i] = x[j];
+    sy[i] = y[j];
+}
+
+// bin_start[b] = first sorted position whose key >= b  (keys sorted ascending)
+__global__ __launch_bounds__(256) void k_bin_start(const uint32_t *__restrict__ keys, int64_t n, int64_t nbins,
+                                                   int32_t *__restrict__ bin_start)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t cur = i < n ? keys[i] : (uint32_t)nbins;
+    uint32_t prev = i > 0 ? keys[i - 1] + 1 : 0;  // first bin not yet closed
+    for (uint32_t b = prev; b <= cur && b <= (uint32_t)nbins; ++b) bin_start[b] = (int32_t)i;
+}
+
+static int build_bins(sc_ctx *c, const double *xy, int64_t n, double target_per_bin, double min_h)
+{
+    SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL, SC_ERR_INVALID, "n=%lld out of range", (long long)n);
+    double xmin = DBL_MAX, xmax = -DBL_MAX, ymin = DBL_MAX, ymax = -DBL_MAX;
+    for (int64_t i = 0; i < n; ++i) {
+        double x = xy[2 * i], y = xy[2 * i + 1];
+        SC_REQUIRE(isfinite(x) && isfinite(y), SC_ERR_INVALID, "coordinate %lld is not finite", (long long)i);
+        xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
+        ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+    }
+    double w = xmax - xmin, hgt = ymax - ymin;
+    double area = (w > 0 ? w : 1.0) * (hgt > 0 ? hgt : 1.0);
+    double h = sqrt(area * target_per_bin / (double)n);
+    if (h < min_h) h = min_h;
+    double ext = w > hgt ? w : hgt;
+    if (!(h > 0)) h = 1.0;
+    // cap the grid at 4096 x 4096 bins
+    if (ext / h > 4096.0) h = ext / 4096.0;
+    int nbx = (int)floor(w / h) + 1, nby = (int)floor(hgt / h) + 1;
+    c->nbx = nbx; c->nby = nby; c->gx0 = xmin; c->gy0 = ymin; c->gh = h;
+    int64_t nbins = (int64_t)nbx * nby;
+
+    SC_TRY(c->e_tmp_data.ensure(sizeof(double) * 2 * (size_t)n, &c->mem));  // staging for AoS upload
+    SC_TRY(c->px.ensure(sizeof(double) * (size_t)n, &c->mem));
+    SC_TRY(c->py.ensure(sizeof(double) * (size_t)n, &c->mem));
+    SC_TRY(c->sx.ensure(sizeof(double) * (size_t)n, &c->mem));
+    SC_TRY(c->sy.ensure(sizeof(double) * (size_t)n, &c->mem));
+    SC_TRY(c->sid.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
+    SC_TRY(c->sid2.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
+    SC_TRY(c->bin_keys.ensure(sizeof(uint32_t) * (size_t)n, &c->mem));
+    SC_TRY(c->bin_keys2.ensure(sizeof(uint32_t) * (size_t)n, &c->mem));
+    SC_TRY(c->bin_start.ensure(sizeof(int32_t) * (size_t)(nbins + 1), &c->mem));
+    SC_HIP(hipMemcpyAsync(c->e_tmp_data.p, xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    unsigned grid = (unsigned)ceil_div64(n, 256);
+    hipLaunchKernelGGL(k_split_xy, dim3(grid), dim3(256), 0, c->stream, c->e_tmp_data.as<double>(),
+                       c->px.as<double>(), c->py.as<double>(), n);
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid), dim3(256), 0, c->stream, c->px.as<double>(), c->py.as<double>(), n,
+                       xmin, ymin, 1.0 / h, nbx, nby, c->bin_keys.as<uint32_t>(), c->sid2.as<int32_t>());
+    int bits = 1;
+    while (((int64_t)1 << bits) < nbins) ++bits;
+    size_t tmp_bytes = 0;
+    SC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->bin_keys.as<uint32_t>(),
+                                              c->bin_keys2.as<uint32_t>(), c->sid2.as<int32_t>(),
+                                              c->sid.as<int32_t>(), (int)n, 0, bits, c->stream));
+    SC_TRY(c->cub_tmp.ensure(tmp_bytes, &c->mem));
+    SC_HIP(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp_bytes, c->bin_keys.as<uint32_t>(),
+                                              c->bin_keys2.as<uint32_t>(), c->sid2.as<int32_t>(),
+                                              c->sid.as<int32_t>(), (int)n, 0, bits, c->stream));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(grid), dim3(256), 0, c->stream, c->px.as<double>(), c->py.as<double>(),
+                       c->sid.as<int32_t>(), n, c->sx.as<double>(), c->sy.as<double>());
+    hipLaunchKernelGGL(k_bin_start, dim3((unsigned)ceil_div64(n + 1, 256)), dim3(256), 0, c->stream,
+                       c->bin_keys2.as<uint32_t>(), n, nbins, c->bin_start.as<int32_t>());
+    SC_HIP(hipGetLastError());
+    c->pts_n = n;
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1: exact kNN
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool cand_better(double d, int id, double ed, int eid)
+{
+    return d < ed || (d == ed && id < eid);
+}
+
+template <int K>
+struct TopK {
+    double d[K];
+    int id[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = DBL_MAX; id[j] = 0x7fffffff; }
+    }
+    // sorted insert of a candidate known to beat the last entry
+    __device__ __forceinline__ void insert(double cd, int cid)
+    {
+        bool b_hi = cand_better(cd, cid, d[K - 1], id[K - 1]);  // vs entry j
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            bool b_lo = cand_better(cd, cid, d[j - 1], id[j - 1]);  // vs entry j-1
+            double nd = b_lo ? d[j - 1] : (b_hi ? cd : d[j]);
+            int ni = b_lo ? id[j - 1] : (b_hi ? cid : id[j]);
+            d[j] = nd;
+            id[j] = ni;
+            b_hi = b_lo;
+        }
+        if (b_hi) { d[0] = cd; id[0] = cid; }
+    }
+    __device__ __forceinline__ double kth(int k) const
+    {
+        double v = d[K - 1];
+#pragma unroll
+        for (int j = 0; j < K; ++j) v = (j == k - 1) ? d[j] : v;
+        return v;
+    }
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn(const double *__restrict__ sx, const double *__restrict__ sy,
+                                             const int32_t *__restrict__ sid,
+                                             const int32_t *__restrict__ bin_start, int64_t n, int k,
+                                             int include_self, double x0, double y0, double h, int nbx, int nby,
+                                             int32_t *__restrict__ idx_out, double *__restrict__ rd_out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double qx = sx[t], qy = sy[t];
+    const int qid = sid[t];
+    const double inv_h = 1.0 / h;
+    const int bx = bin_coord(qx, x0, inv_h, nbx), by = bin_coord(qy, y0, inv_h, nby);
+    TopK<K> best;
+    best.init();
+    double kth = DBL_MAX;
+    const int rmax = (nbx > nby ? nbx : nby);
+    const double slack = 1e-9 * h;
+    for (int r = 0; r <= rmax; ++r) {
+        const int ylo = by - r, yhi = by + r, xlo = bx - r, xhi = bx + r;
+        const int cxlo = xlo < 0 ? 0 : xlo, cxhi = xhi >= nbx ? nbx - 1 : xhi;
+        for (int yy = (ylo < 0 ? 0 : ylo); yy <= (yhi >= nby ? nby - 1 : yhi); ++yy) {
+            const bool full = (yy == ylo) || (yy == yhi);
+            // full row of the ring: bins [cxlo, cxhi]; interior rows: only the two end bins
+            for (int seg = 0; seg < (full ? 1 : 2); ++seg) {
+                int b0, b1;
+                if (full) { b0 = cxlo; b1 = cxhi; }
+                else if (seg == 0) { if (xlo < 0) continue; b0 = b1 = xlo; }
+                else { if (xhi >= nbx || r == 0) continue; b0 = b1 = xhi; }
+                const int s0 = bin_start[yy * nbx + b0], s1 = bin_start[yy * nbx + b1 + 1];
+                for (int s = s0; s < s1; ++s) {
+                    const int cid = sid[s];
+                    const double dx = qx - sx[s], dy = qy - sy[s];
+                    const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                    if (cid == qid && !include_self) continue;
+                    if (cand_better(d, cid, best.d[K - 1], best.id[K - 1])) {
+                        best.insert(d, cid);
+                        kth = best.kth(k);
+                    }
+                }
+            }
+        }
+        // distance from the query to the nearest unvisited region
+        const bool l_out = xlo <= 0, r_out = xhi >= nbx - 1, b_out = ylo <= 0, t_out = yhi >= nby - 1;
+        if (l_out && r_out && b_out && t_out) break;  // everything visited
+        double m = DBL_MAX;
+        if (!l_out) m = fmin(m, qx - (x0 + (double)xlo * h));
+        if (!r_out) m = fmin(m, (x0 + (double)(xhi + 1) * h) - qx);
+        if (!b_out) m = fmin(m, qy - (y0 + (double)ylo * h));
+        if (!t_out) m = fmin(m, (y0 + (double)(yhi + 1) * h) - qy);
+        m -= slack;
+        if (m > 0.0 && kth < m * m) break;
+    }
+    // scatter to the original query order
+    int32_t *o = idx_out + (int64_t)qid * k;
+    double *od = rd_out ? rd_out + (int64_t)qid * k : nullptr;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k) {
+            o[j] = best.id[j];
+            if (od) od[j] = best.d[j];
+        }
+}
+
+template <int K>
+static void launch_knn(sc_ctx *c, int64_t n, int k, int include_self)
+{
+    hipLaunchKernelGGL(k_knn<K>, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->sx.as<double>(),
+                       c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), n, k, include_self,
+                       c->gx0, c->gy0, c->gh, c->nbx, c->nby, c->knn_idx.as<int32_t>(), c->knn_rd.as<double>());
+}
+
+extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int include_self, int32_t *idx_out,
+                         double *rdist_out)
+{
+    SC_REQUIRE(c && xy, SC_ERR_INVALID, "sc_knn_2d: null pointer");
+    SC_REQUIRE(k >= 1 && k <= 64, SC_ERR_INVALID, "sc_knn_2d: k=%d unsupported (1..64)", k);
+    SC_REQUIRE(n >= 1, SC_ERR_INVALID, "sc_knn_2d: n must be >= 1");
+    SC_REQUIRE((int64_t)k <= n - (include_self ? 0 : 1), SC_ERR_INVALID,
+               "sc_knn_2d: k=%d needs more than the %lld available points", k, (long long)n);
+    SC_HIP(hipSetDevice(c->device));
+    c->knn_n = 0;
+    SC_TRY(build_bins(c, xy, n, 0.5 * (k + 1) > 4.0 ? 0.5 * (k + 1) : 4.0, 0.0));
+    SC_TRY(c->knn_idx.ensure(sizeof(int32_t) * (size_t)n * k, &c->mem));
+    SC_TRY(c->knn_rd.ensure(sizeof(double) * (size_t)n * k, &c->mem));
+    {
+        KernelTimerScope ts(c, SC_K_KNN);
+        if (k <= 8) launch_knn<8>(c, n, k, include_self);
+        else if (k <= 16) launch_knn<16>(c, n, k, include_self);
+        else if (k <= 32) launch_knn<32>(c, n, k, include_self);
+        else launch_knn<64>(c, n, k, include_self);
+    }
+    SC_HIP(hipGetLastError());
+    if (idx_out)
+        SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * (size_t)n * k, hipMemcpyDeviceToHost,
+                              c->stream));
+    if (rdist_out)
+        SC_HIP(hipMemcpyAsync(rdist_out, c->knn_rd.p, sizeof(double) * (size_t)n * k, hipMemcpyDeviceToHost,
+                              c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->knn_n = n;
+    c->knn_k = k;
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2: radius graph (closed ball, self removed), two passes
+// ------------------------------------------------------------------------------------------------
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_radius(const double *__restrict__ sx, const double *__restrict__ sy,
+                                                const int32_t *__restrict__ sid,
+                                                const int32_t *__restrict__ bin_start, int64_t n, double r2,
+                                                int rings, double x0, double y0, double h, int nbx, int nby,
+                                                long long *__restrict__ counts,
+                                                const long long *__restrict__ indptr,
+                                                int32_t *__restrict__ indices)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double qx = sx[t], qy = sy[t];
+    const int qid = sid[t];
+    const double inv_h = 1.0 / h;
+    const int bx = bin_coord(qx, x0, inv_h, nbx), by = bin_coord(qy, y0, inv_h, nby);
+    const int ylo = by - rings < 0 ? 0 : by - rings, yhi = by + rings >= nby ? nby - 1 : by + rings;
+    const int xlo = bx - rings < 0 ? 0 : bx - rings, xhi = bx + rings >= nbx ? nbx - 1 : bx + rings;
+    long long cnt = 0;
+    int32_t *row = FILL ? indices + indptr[qid] : nullptr;
+    for (int yy = ylo; yy <= yhi; ++yy) {
+        const int s0 = bin_start[yy * nbx + xlo], s1 = bin_start[yy * nbx + xhi + 1];
+        for (int s = s0; s < s1; ++s) {
+            const int cid = sid[s];
+            const double dx = qx - sx[s], dy = qy - sy[s];
+            const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+            if (cid != qid && d <= r2) {
+                if (FILL) {
+                    // insertion keeps the row ascending by index
+                    long long j = cnt;
+                    while (j > 0 && row[j - 1] > cid) { row[j] = row[j - 1]; --j; }
+                    row[j] = cid;
+                }
+                ++cnt;
+            }
+        }
+    }
+    if (!FILL) counts[qid] = cnt;
+}
+
+extern "C" int sc_radius_count_2d(sc_ctx *c, const double *xy, int64_t n, double radius, int64_t *indptr_out)
+{
+    SC_REQUIRE(c && xy && indptr_out, SC_ERR_INVALID, "sc_radius_count_2d: null pointer");
+    SC_REQUIRE(radius > 0 && isfinite(radius), SC_ERR_INVALID, "radius must be > 0, got %g", radius);
+    SC_HIP(hipSetDevice(c->device));
+    c->radius = -1.0;
+    // bins no smaller than the radius: a 3x3 window always covers the closed ball
+    SC_TRY(build_bins(c, xy, n, 4.0, radius));
+    int rings = (int)ceil(radius / c->gh * (1.0 + 1e-9));
+    if (rings < 1) rings = 1;
+    SC_TRY(c->rad_indptr.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->gt_cursor.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
+    long long *counts = c->gt_cursor.as<long long>();
+    SC_HIP(hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)(n + 1), c->stream));
+    hipLaunchKernelGGL(k_radius<false>, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->sx.as<double>(), c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), n,
+                       radius * radius, rings, c->gx0, c->gy0, c->gh, c->nbx, c->nby, counts,
+                       (const long long *)nullptr, (int32_t *)nullptr);
+    SC_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    SC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts, c->rad_indptr.as<long long>(), (int)(n + 1),
+                                            c->stream));
+    SC_TRY(c->cub_tmp.ensure(tmp_bytes, &c->mem));
+    SC_HIP(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, counts, c->rad_indptr.as<long long>(),
+                                            (int)(n + 1), c->stream));
+    SC_HIP(hipMemcpyAsync(indptr_out, c->rad_indptr.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost,
+                          c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->radius = radius;
+    return SC_OK;
+}
+
+extern "C" int sc_radius_fill_2d(sc_ctx *c, int64_t nnz, int32_t *indices_out)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->radius > 0 && c->pts_n > 0, SC_ERR_STATE, "sc_radius_fill_2d: call sc_radius_count_2d first");
+    int64_t n = c->pts_n;
+    long long total = 0;
+    SC_HIP(hipMemcpyAsync(&total, c->rad_indptr.as<long long>() + n, sizeof(long long), hipMemcpyDeviceToHost,
+                          c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    SC_REQUIRE(total == nnz, SC_ERR_INVALID, "sc_radius_fill_2d: nnz=%lld but the count pass found %lld",
+               (long long)nnz, total);
+    SC_REQUIRE(nnz == 0 || indices_out, SC_ERR_INVALID, "sc_radius_fill_2d: null output");
+    SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    int rings = (int)ceil(c->radius / c->gh * (1.0 + 1e-9));
+    if (rings < 1) rings = 1;
+    hipLaunchKernelGGL(k_radius<true>, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->sx.as<double>(), c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), n,
+                       c->radius * c->radius, rings, c->gx0, c->gy0, c->gh, c->nbx, c->nby, (long long *)nullptr,
+                       c->rad_indptr.as<long long>(), c->g_indices.as<int32_t>());
+    SC_HIP(hipGetLastError());
+    if (nnz > 0)
+        SC_HIP(hipMemcpyAsync(indices_out, c->g_indices.p, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost,
+                              c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    // the fill pass used g_indices as scratch: the active graph (if any) is gone
+    c->g_n = 0;
+    c->g_nnz = 0;
+    c->gt_valid = false;
+    c->s0_valid = false;
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A3: CSR graph
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_check_csr(const long long *__restrict__ indptr,
+                                                   const int32_t *__restrict__ indices, int64_t n,
+                                                   int *__restrict__ flag)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = 0;
+    for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
+        int32_t j = indices[e];
+        if (j < 0 || j >= n) bad |= 1;
+        if (e > indptr[i] && indices[e - 1] >= j) bad |= 2;
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t *indices, const double *data,
+                                int64_t n, int64_t nnz)
+{
+    SC_REQUIRE(c && indptr, SC_ERR_INVALID, "sc_graph_set_csr: null pointer");
+    SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL && nnz >= 0, SC_ERR_INVALID, "sc_graph_set_csr: bad shape");
+    SC_REQUIRE(nnz == 0 || (indices && data), SC_ERR_INVALID, "sc_graph_set_csr: null indices/data");
+    SC_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, SC_ERR_INVALID, "sc_graph_set_csr: indptr does not span nnz");
+    for (int64_t i = 0; i < n; ++i)
+        SC_REQUIRE(indptr[i + 1] >= indptr[i], SC_ERR_INVALID, "sc_graph_set_csr: indptr not monotone");
+    SC_HIP(hipSetDevice(c->device));
+    c->g_n = 0;
+    c->gt_valid = false;
+    c->s0_valid = false;
+    SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    SC_TRY(c->perm_flag.ensure(sizeof(int), &c->mem));
+    SC_HIP(hipMemcpyAsync(c->g_indptr.p, indptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {
+        SC_HIP(hipMemcpyAsync(c->g_indices.p, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                              c->stream));
+        SC_HIP(hipMemcpyAsync(c->g_data.p, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    }
+    SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_check_csr, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), n, c->perm_flag.as<int>());
+    int flag = 0;
+    SC_HIP(hipMemcpyAsync(&flag, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    SC_REQUIRE(!(flag & 1), SC_ERR_INVALID, "sc_graph_set_csr: column index out of range");
+    SC_REQUIRE(!(flag & 2), SC_ERR_INVALID,
+               "sc_graph_set_csr: rows must have strictly ascending column indices (sort_indices/sum_duplicates)");
+    c->g_n = n;
+    c->g_nnz = nnz;
+    return SC_OK;
+}
+
+// rows of the kNN result, re-ordered ascending by column index (as scipy's COO->CSR gives, AC:404)
+__global__ __launch_bounds__(256) void k_knn_to_csr(const int32_t *__restrict__ knn, int64_t n, int k, double w,
+                                                    long long *__restrict__ indptr, int32_t *__restrict__ indices,
+                                                    double *__restrict__ data)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    indptr[i] = i * k;
+    if (i == n) return;
+    int32_t *row = indices + i * k;
+    for (int j = 0; j < k; ++j) {
+        int32_t v = knn[i * k + j];
+        int m = j;
+        while (m > 0 && row[m - 1] > v) { row[m] = row[m - 1]; --m; }
+        row[m] = v;
+        data[i * k + j] = w;
+    }
+}
+
+extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->knn_n > 0, SC_ERR_STATE, "sc_graph_from_knn: no kNN result (call sc_knn_2d first)");
+    int64_t n = c->knn_n, nnz = n * c->knn_k;
+    c->g_n = 0;
+    c->gt_valid = false;
+    c->s0_valid = false;
+    SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)nnz, &c->mem));
+    SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)nnz, &c->mem));
+    hipLaunchKernelGGL(k_knn_to_csr, dim3((unsigned)ceil_div64(n + 1, 256)), dim3(256), 0, c->stream,
+                       c->knn_idx.as<int32_t>(), n, c->knn_k, weight, c->g_indptr.as<long long>(),
+                       c->g_indices.as<int32_t>(), c->g_data.as<double>());
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->g_n = n;
+    c->g_nnz = nnz;
+    return SC_OK;
+}
+
+extern "C" int sc_graph_shape(sc_ctx *c, int64_t *n, int64_t *nnz)
+{
+    SC_REQUIRE(c && n && nnz, SC_ERR_INVALID, "null pointer");
+    *n = c->g_n;
+    *nnz = c->g_nnz;
+    return SC_OK;
+}
+
+extern "C" int sc_graph_get(sc_ctx *c, int64_t *indptr_out, int32_t *indices_out, double *data_out)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "sc_graph_get: no graph set");
+    if (indptr_out)
+        SC_HIP(hipMemcpyAsync(indptr_out, c->g_indptr.p, sizeof(int64_t) * (size_t)(c->g_n + 1), hipMemcpyDeviceToHost,
+                              c->stream));
+    if (indices_out && c->g_nnz)
+        SC_HIP(hipMemcpyAsync(indices_out, c->g_indices.p, sizeof(int32_t) * (size_t)c->g_nnz, hipMemcpyDeviceToHost,
+                              c->stream));
+    if (data_out && c->g_nnz)
+        SC_HIP(hipMemcpyAsync(data_out, c->g_data.p, sizeof(double) * (size_t)c->g_nnz, hipMemcpyDeviceToHost,
+                              c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// ---- transpose (deterministic: counting sort by column, rows then sorted by source row) ----------
+
+__global__ __launch_bounds__(256) void k_col_count(const int32_t *__restrict__ indices, int64_t nnz,
+                                                   unsigned long long *__restrict__ cnt)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) atomicAdd(&cnt[indices[e]], 1ull);
+}
+
+// one thread per source row i (ascending e): slot claimed with an atomic cursor; rows of the
+// transpose are sorted afterwards so that the final layout does not depend on the claim order
+__global__ __launch_bounds__(256) void k_transpose_fill(const long long *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        const double *__restrict__ data, int64_t n,
+                                                        unsigned long long *__restrict__ cursor,
+                                                        int32_t *__restrict__ t_indices, double *__restrict__ t_data)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
+        unsigned long long pos = atomicAdd(&cursor[indices[e]], 1ull);
+        t_indices[pos] = (int32_t)i;
+        t_data[pos] = data[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sort_rows(const long long *__restrict__ indptr, int32_t *__restrict__ indices,
+                                                   double *__restrict__ data, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long e0 = indptr[i], e1 = indptr[i + 1];
+    for (long long a = e0 + 1; a < e1; ++a) {
+        int32_t v = indices[a];
+        double w = data[a];
+        long long b = a;
+        while (b > e0 && indices[b - 1] > v) { indices[b] = indices[b - 1]; data[b] = data[b - 1]; --b; }
+        indices[b] = v;
+        data[b] = w;
+    }
+}
+
+int sc_graph_ensure_transpose(sc_ctx *c)
+{
+    if (c->gt_valid) return SC_OK;
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    int64_t n = c->g_n, nnz = c->g_nnz;
+    SC_TRY(c->gt_indptr.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->gt_cursor.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->gt_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    SC_TRY(c->gt_data.ensure(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    unsigned long long *cur = c->gt_cursor.as<unsigned long long>();
+    SC_HIP(hipMemsetAsync(cur, 0, sizeof(long long) * (size_t)(n + 1), c->stream));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_col_count, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, c->stream,
+                           c->g_indices.as<int32_t>(), nnz, cur);
+    size_t tmp_bytes = 0;
+    SC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (long long *)cur, c->gt_indptr.as<long long>(),
+                                            (int)(n + 1), c->stream));
+    SC_TRY(c->cub_tmp.ensure(tmp_bytes, &c->mem));
+    SC_HIP(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, (long long *)cur, c->gt_indptr.as<long long>(),
+                                            (int)(n + 1), c->stream));
+    SC_HIP(hipMemcpyAsync(cur, c->gt_indptr.p, sizeof(long long) * (size_t)(n + 1), hipMemcpyDeviceToDevice,
+                          c->stream));
+    hipLaunchKernelGGL(k_transpose_fill, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), c->g_data.as<double>(), n, cur,
+                       c->gt_indices.as<int32_t>(), c->gt_data.as<double>());
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->gt_indptr.as<long long>(), c->gt_indices.as<int32_t>(), c->gt_data.as<double>(), n);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->gt_valid = true;
+    return SC_OK;
+}
+
+// ---- moments ---------------------------------------------------------------------------------------
+
+#define MOM_ROWS_PER_BLOCK 1024
+
+// per block partials of: s0 (sum w), t2 (sum over W-edges of the (w_ij + w_ji)^2 contributions), s2
+__global__ __launch_bounds__(256) void k_moments(const long long *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices,
+                                                 const double *__restrict__ data,
+                                                 const long long *__restrict__ t_indptr,
+                                                 const double *__restrict__ t_data, int64_t n,
+                                                 double *__restrict__ partial)
+{
+    __shared__ double sh[3][256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    int64_t r0 = (int64_t)blockIdx.x * MOM_ROWS_PER_BLOCK;
+    int64_t r1 = r0 + MOM_ROWS_PER_BLOCK < n ? r0 + MOM_ROWS_PER_BLOCK : n;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+        double rs = 0.0, cs = 0.0;
+        for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
+            int32_t j = indices[e];
+            double w = data[e];
+            rs += w;
+            // look for the reverse edge (j -> i) in row j (ascending columns)
+            long long lo = indptr[j], hi = indptr[j + 1];
+            double wr = 0.0;
+            bool found = false;
+            while (lo < hi) {
+                long long mid = (lo + hi) >> 1;
+                int32_t v = indices[mid];
+                if (v < i) lo = mid + 1;
+                else if (v > i) hi = mid;
+                else { wr = data[mid]; found = true; break; }
+            }
+            // (i,j) and (j,i) both stored: this edge contributes (w_ij + w_ji)^2 once (the mirror edge
+            // contributes the same again when its own row is visited); one-directional: both (i,j)
+            // and (j,i) of W + W^T equal w_ij
+            a1 += found ? (w + wr) * (w + wr) : 2.0 * w * w;
+        }
+        for (long long e = t_indptr[i]; e < t_indptr[i + 1]; ++e) cs += t_data[e];
+        a0 += rs;
+        a2 += (rs + cs) * (rs + cs);
+    }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int m = 0; m < 3; ++m) sh[m][threadIdx.x] += sh[m][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[(int64_t)blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+static int graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
+{
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    SC_TRY(sc_graph_ensure_transpose(c));
+    int64_t n = c->g_n;
+    int blocks = (int)ceil_div64(n, MOM_ROWS_PER_BLOCK);
+    SC_TRY(c->red_tmp.ensure(sizeof(double) * 3 * (size_t)blocks, &c->mem));
+    hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                       c->g_indices.as<int32_t>(), c->g_data.as<double>(), c->gt_indptr.as<long long>(),
+                       c->gt_data.as<double>(), n, c->red_tmp.as<double>());
+    SC_HIP(hipGetLastError());
+    std::vector<double> h((size_t)blocks * 3);
+    SC_HIP(hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int b = 0; b < blocks; ++b) { a0 += h[3 * b]; a1 += h[3 * b + 1]; a2 += h[3 * b + 2]; }
+    *s0 = a0; *s1 = a1 / 2.0; *s2 = a2;
+    c->s0 = a0;
+    c->s0_valid = true;
+    return SC_OK;
+}
+
+extern "C" int sc_graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
+{
+    SC_REQUIRE(c && s0 && s1 && s2, SC_ERR_INVALID, "null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    return graph_moments(c, s0, s1, s2);
+}
+
+int sc_graph_ensure_s0(sc_ctx *c)
+{
+    if (c->s0_valid) return SC_OK;
+    double a, b, d;
+    return graph_moments(c, &a, &b, &d);
+}
+
+// y[i] = sum_e w[e] * x[col[e]]  for one contiguous vector
+__global__ __launch_bounds__(256) void k_spmv_vec(const long long *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices, const double *__restrict__ w,
+                                                  const double *__restrict__ x, double *__restrict__ y, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (long long e = indptr[i]; e < indptr[i + 1]; ++e) s = __dadd_rn(s, __dmul_rn(w[e], x[indices[e]]));
+    y[i] = s;
+}
+
+void sc_launch_spmv_vec(sc_ctx *c, const int64_t *indptr, const int32_t *indices, const double *w, const double *x,
+                        double *y, int64_t n)
+{
+    hipLaunchKernelGGL(k_spmv_vec, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       (const long long *)indptr, indices, w, x, y, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9: neighbourhood composition on the active graph's pattern
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_profile(const long long *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices,
+                                                 const int32_t *__restrict__ labels, int64_t n, int n_types,
+                                                 float *__restrict__ counts, unsigned long long *__restrict__ n_empty)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *row = counts + i * n_types;
+    long long e0 = indptr[i], e1 = indptr[i + 1];
+    for (long long e = e0; e < e1; ++e) row[labels[indices[e]]] += 1.0f;
+    if (e1 == e0) atomicAdd(n_empty, 1ull);
+}
+
+extern "C" int sc_profile_counts(sc_ctx *c, const int32_t *labels, int64_t n, int32_t n_types, float *counts_out,
+                                 int64_t *n_empty_out)
+{
+    SC_REQUIRE(c && labels && counts_out, SC_ERR_INVALID, "sc_profile_counts: null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "sc_profile_counts: no graph set");
+    SC_REQUIRE(n == c->g_n, SC_ERR_INVALID, "sc_profile_counts: %lld labels for a graph of %lld cells", (long long)n,
+               (long long)c->g_n);
+    SC_REQUIRE(n_types >= 1 && n_types <= 65536, SC_ERR_INVALID, "n_types out of range");
+    for (int64_t i = 0; i < n; ++i)
+        SC_REQUIRE(labels[i] >= 0 && labels[i] < n_types, SC_ERR_INVALID, "label %d of cell %lld out of range",
+                   labels[i], (long long)i);
+    size_t cbytes = sizeof(float) * (size_t)n * (size_t)n_types;
+    SC_TRY(c->lee_a.ensure(cbytes, &c->mem));
+    SC_TRY(c->lee_pairs.ensure(sizeof(int32_t) * (size_t)n + 16, &c->mem));
+    SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
+    SC_HIP(hipMemcpyAsync(c->lee_pairs.p, labels, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemsetAsync(c->lee_a.p, 0, cbytes, c->stream));
+    SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_profile, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
+                       c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), c->lee_pairs.as<int32_t>(), n,
+                       (int)n_types, c->lee_a.as<float>(), c->perm_flag.as<unsigned long long>());
+    SC_HIP(hipGetLastError());
+    unsigned long long empty = 0;
+    SC_HIP(hipMemcpyAsync(counts_out, c->lee_a.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(&empty, c->perm_flag.p, sizeof(empty), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    if (n_empty_out) *n_empty_out = (int64_t)empty;
+    if (empty) {
+        sc_set_error("%llu cells have empty neighborhood profiles", empty);
+        return SC_ERR_EMPTY;
+    }
+    return SC_OK;
+}

@@ -1,0 +1,16 @@
+"""MI355X-native spatial statistics: the hot path of ``spatialcore.spatial``
+(reference src/spatialcore/spatial/__init__.py:11-52) behind the same function names."""
+
+from spatialcore_amd.spatial.autocorrelation import (
+    build_spatial_weights,
+    lees_l,
+    morans_i,
+)
+from spatialcore_amd.spatial.neighborhoods import compute_neighborhood_profile
+
+__all__ = [
+    "morans_i",
+    "lees_l",
+    "build_spatial_weights",
+    "compute_neighborhood_profile",
+]

@@ -1,0 +1,403 @@
+"""Spatial autocorrelation on MI355X: Moran's I and Lee's L with permutation significance.
+
+Drop-in mirror of the reference's ``spatialcore.spatial.autocorrelation`` public functions
+(same names, keyword arguments, defaults, outputs and error messages;
+reference src/spatialcore/spatial/autocorrelation.py, abbreviated ``AC`` below).  All arithmetic on
+the path runs in hand-written HIP kernels behind the C ABI of ``include/spatialcore_hip.h``; there is
+no CPU fallback -- without the shared library or a gfx950 device the functions raise.
+
+Extra keyword (keyword-only, default preserves reference behaviour): ``device`` = GPU ordinal.
+"""
+
+from __future__ import annotations
+
+import time
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import pandas as pd
+from scipy import sparse, stats
+from scipy.sparse import csr_matrix
+
+from spatialcore_amd import _lib
+from spatialcore_amd._logging import get_logger
+from spatialcore_amd._metadata import update_metadata
+
+logger = get_logger("spatial.autocorrelation")
+
+# Quadrant encoding (AC:57-58): 0=NS, 1=HH, 2=LL, 3=HL, 4=LH
+QUADRANT_LABELS = {0: "NS", 1: "HH", 2: "LL", 3: "HL", 4: "LH"}
+
+
+# =============================================================================================
+# helpers
+# =============================================================================================
+
+
+def _require_spatial(adata, spatial_key: str) -> np.ndarray:
+    if spatial_key not in adata.obsm:
+        raise ValueError(f"adata.obsm['{spatial_key}'] not found. Spatial coordinates are required.")
+    coords = np.asarray(adata.obsm[spatial_key])
+    if coords.ndim != 2 or coords.shape[1] < 2:
+        raise ValueError(f"adata.obsm['{spatial_key}'] must have shape (n_cells, 2), got {coords.shape}")
+    if coords.shape[1] > 2:
+        raise ValueError("only 2-D coordinates are supported by the MI355X path "
+                         f"(adata.obsm['{spatial_key}'] has {coords.shape[1]} columns)")
+    return np.ascontiguousarray(coords, dtype=np.float64)
+
+
+def _check_counts(n_neighbors: int, n_permutations: int) -> None:
+    if n_neighbors < 1:
+        raise ValueError(f"n_neighbors must be >= 1, got {n_neighbors}")
+    if n_permutations < 0:
+        raise ValueError(f"n_permutations must be >= 0, got {n_permutations}")
+
+
+def _resolve_genes(adata, genes, warn_suffix: str) -> List[str]:
+    if genes is None:
+        names = list(adata.var_names)
+        logger.warning(f"No genes specified, analyzing all {len(names)} genes. {warn_suffix}")
+    elif isinstance(genes, str):
+        names = [genes]
+    else:
+        names = list(genes)
+    missing = set(names) - set(adata.var_names)
+    if missing:
+        raise ValueError(f"Genes not found in adata.var_names: {list(missing)[:10]}")
+    return names
+
+
+def _expression(adata, layer: Optional[str]):
+    return adata.layers[layer] if layer is not None else adata.X
+
+
+def _unique_columns(adata, names: List[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """Column ids of the distinct genes (first-seen order) and, per requested name, its slot."""
+    slot, cols, where = {}, [], []
+    for g in names:
+        if g not in slot:
+            slot[g] = len(cols)
+            cols.append(int(adata.var_names.get_loc(g)))
+        where.append(slot[g])
+    return np.asarray(cols, dtype=np.int32), np.asarray(where, dtype=np.int64)
+
+
+def _knn_weights_f32(ctx, coords: np.ndarray, n_neighbors: int, include_self: bool = False) -> float:
+    """kNN on the device + the reference's float32 row-normalised weights (AC:393-413) as the active
+    graph.  Returns the (float32-valued) weight."""
+    k = n_neighbors + 1 if include_self else n_neighbors
+    ctx.knn(coords, k, include_self=include_self, fetch=False)
+    w = float(np.float32(1.0) / np.float32(k))
+    ctx.graph_from_knn(w)
+    return w
+
+
+# =============================================================================================
+# FDR / quadrants (AC:132-265) -- O(n) bookkeeping on per-cell outputs
+# =============================================================================================
+
+
+def _fdr_correction_bh(p_values: np.ndarray) -> np.ndarray:
+    """Benjamini-Hochberg adjusted p-values (AC:132-164)."""
+    n = len(p_values)
+    if n == 0:
+        return p_values.copy()
+    order = np.argsort(p_values)
+    adj = p_values[order] * n / np.arange(1, n + 1)
+    adj = np.minimum.accumulate(adj[::-1])[::-1]
+    out = np.empty(n)
+    out[order] = adj
+    return np.clip(out, 0, 1)
+
+
+def _fdr_correction_bonferroni(p_values: np.ndarray) -> np.ndarray:
+    """Bonferroni adjusted p-values (AC:167-183)."""
+    n = len(p_values)
+    if n == 0:
+        return p_values.copy()
+    return np.clip(p_values * n, 0, 1)
+
+
+def _apply_fdr_correction(p_values: np.ndarray, method: str) -> np.ndarray:
+    if method == "none":
+        return p_values.copy()
+    if method == "bonferroni":
+        return _fdr_correction_bonferroni(p_values)
+    if method == "fdr_bh":
+        return _fdr_correction_bh(p_values)
+    raise ValueError(f"Unknown FDR method: {method}")
+
+
+def _classify_quadrants(z_values, lag_values, p_values=None, alpha: float = 0.05) -> np.ndarray:
+    """LISA quadrants as int8 (AC:219-265): 1=HH, 2=LL, 3=HL, 4=LH, 0=NS / not significant."""
+    q = np.zeros(np.shape(z_values), dtype=np.int8)
+    q[(z_values > 0) & (lag_values > 0)] = 1
+    q[(z_values < 0) & (lag_values < 0)] = 2
+    q[(z_values > 0) & (lag_values < 0)] = 3
+    q[(z_values < 0) & (lag_values > 0)] = 4
+    if p_values is not None:
+        q[p_values >= alpha] = 0
+    return q
+
+
+# =============================================================================================
+# build_spatial_weights (AC:342-413)
+# =============================================================================================
+
+
+def build_spatial_weights(adata, n_neighbors: int = 6, spatial_key: str = "spatial",
+                          include_self: bool = False, *, device: int = 0) -> csr_matrix:
+    """Row-normalised sparse kNN weights, float32 CSR, each row sums to 1 (AC:342-413).
+
+    Neighbours come from the exact GPU kNN (ordered by squared distance, then index: identical to
+    the reference's ball tree on tie-free coordinates); columns are ascending within a row, as the
+    reference's COO->CSR conversion leaves them.
+    """
+    coords = _require_spatial(adata, spatial_key)
+    n_cells = coords.shape[0]
+    logger.debug(f"Building spatial weights: {n_cells:,} cells, k={n_neighbors}")
+    ctx = _lib.default_context(device)
+    _knn_weights_f32(ctx, coords, n_neighbors, include_self)
+    indptr, indices, data = ctx.get_graph()
+    W = csr_matrix((data.astype(np.float32), indices, indptr), shape=(n_cells, n_cells))
+    logger.debug(f"Spatial weights: nnz={W.nnz:,}")
+    return W
+
+
+# =============================================================================================
+# Global Moran's I (AC:421-648)
+# =============================================================================================
+
+
+def _squidpy_neighbors(ctx, adata, coords, n_neighbors: int, spatial_key: str):
+    """What ``sq.gr.spatial_neighbors(adata, n_neighs=k, coord_type='generic')`` leaves behind
+    (AC:565-570) [upstream squidpy]: binary float64 connectivities + euclidean distances in
+    ``adata.obsp`` and a ``uns['spatial_neighbors']`` record; the row-normalised graph (squidpy's
+    ``transformation=True``) becomes the active device graph."""
+    n = coords.shape[0]
+    idx, rd = ctx.knn(coords, n_neighbors, return_distance=True)
+    ctx.graph_from_knn(1.0 / n_neighbors)
+    indptr = np.arange(0, n * n_neighbors + 1, n_neighbors, dtype=np.int64)
+    conn = csr_matrix((np.ones(idx.size, dtype=np.float64), idx.reshape(-1), indptr), shape=(n, n))
+    dist = csr_matrix((np.sqrt(rd).reshape(-1), idx.reshape(-1), indptr.copy()), shape=(n, n))
+    adata.obsp["spatial_connectivities"] = conn
+    adata.obsp["spatial_distances"] = dist
+    adata.uns["spatial_neighbors"] = {
+        "connectivities_key": "spatial_connectivities",
+        "distances_key": "spatial_distances",
+        "params": {"n_neighbors": n_neighbors, "coord_type": "generic", "radius": None, "transform": None},
+    }
+
+
+def _upload_existing_graph(ctx, g) -> None:
+    """Row-normalise (l1, as squidpy's transformation=True does) and upload a user graph."""
+    g = csr_matrix(g, dtype=np.float64, copy=True)
+    g.sum_duplicates()
+    g.sort_indices()
+    rs = np.abs(g).sum(axis=1).A1 if hasattr(np.abs(g).sum(axis=1), "A1") else np.asarray(np.abs(g).sum(axis=1)).ravel()
+    rs[rs == 0] = 1.0
+    g.data = g.data / np.repeat(rs, np.diff(g.indptr))
+    ctx.set_graph_csr(g.indptr, g.indices, g.data, g.shape[0])
+
+
+def _norm_sf_cdf(z: np.ndarray) -> np.ndarray:
+    """[upstream squidpy] one-sided normal p: 1 - cdf(z) for z > 0, cdf(z) otherwise."""
+    p = np.empty(z.shape)
+    pos = z > 0
+    p[pos] = 1 - stats.norm.cdf(z[pos])
+    p[~pos] = stats.norm.cdf(z[~pos])
+    return p
+
+
+def morans_i(
+    adata,
+    genes: Optional[Union[str, List[str]]] = None,
+    layer: Optional[str] = None,
+    spatial_key: str = "spatial",
+    n_neighbors: int = 6,
+    n_permutations: int = 10,
+    seed: int = 0,
+    key_added: str = "morans_i",
+    copy: bool = False,
+    use_existing_graph: bool = False,
+    *,
+    device: int = 0,
+):
+    """Global Moran's I with permutation p-values (AC:421-648).
+
+    Same contract as the reference: results go to ``adata.uns[key_added]`` as a DataFrame with
+    columns ``gene, I, expected_I, z_score, p_value`` in input gene order; the kNN graph is left in
+    ``adata.obsp['spatial_connectivities'|'spatial_distances']``; one provenance entry is appended.
+
+    The reference delegates the arithmetic to squidpy (``spatial_neighbors`` +
+    ``spatial_autocorr(mode='moran', n_perms=P, n_jobs=1, seed=seed)``, AC:565-583).  Here it runs on
+    the GPU: exact kNN, row-normalised lag, and ``P`` permutations drawn from the numpy-exact
+    ``default_rng(seed).permutation(n)`` stream, each scored as
+    ``sum_i z_i * lag[perm[i]]`` (identical to scoring the row-permuted graph).
+    """
+    start_time = time.time()
+    coords = _require_spatial(adata, spatial_key)
+    _check_counts(n_neighbors, n_permutations)
+    adata = adata.copy() if copy else adata
+    gene_names = _resolve_genes(adata, genes, "This may be slow for large datasets.")
+    n_cells, n_genes = adata.n_obs, len(gene_names)
+    logger.info(f"Computing Global Moran's I: {n_cells:,} cells, {n_genes} genes, "
+                f"k={n_neighbors}, permutations={n_permutations}")
+
+    ctx = _lib.default_context(device)
+    if use_existing_graph and "spatial_connectivities" in adata.obsp:
+        logger.info("Using existing spatial connectivity graph (use_existing_graph=True)")
+        _upload_existing_graph(ctx, adata.obsp["spatial_connectivities"])
+    else:
+        logger.debug(f"Building spatial neighbors graph (k={n_neighbors})")
+        _squidpy_neighbors(ctx, adata, coords, n_neighbors, spatial_key)
+
+    cols, where = _unique_columns(adata, gene_names)
+    ctx.set_expression(_expression(adata, layer), cols)
+    if n_permutations > 0:
+        # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1
+        words = _lib.rng_state_words(np.random.default_rng(seed))
+        ctx.generate_permutations(words, n_cells, n_permutations)
+    out = ctx.moran(n_permutations, return_sims=False)
+    score = out["I"]
+
+    # analytic moments under normality [upstream squidpy _analytic_pval]
+    s0, s1, s2 = ctx.graph_moments()
+    n = float(n_cells)
+    expected_I = -1 / (n_cells - 1)
+    var_norm = (n * n * s1 - n * s2 + 3 * s0 * s0) / ((n - 1) * (n + 1) * s0 * s0) - (1.0 / (n - 1)) ** 2
+    if n_permutations > 0:
+        large = out["count_ge"].copy()
+        flip = (n_permutations - large) < large
+        large[flip] = n_permutations - large[flip]
+        p_all = (large + 1) / (n_permutations + 1)
+    else:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            p_all = _norm_sf_cdf((score - expected_I) / np.sqrt(var_norm))
+
+    results = []
+    for gene_name, u in zip(gene_names, where):
+        I_value = float(score[u])
+        z_score = float((I_value - expected_I) / np.sqrt(var_norm)) if var_norm > 0 else 0.0
+        results.append({"gene": gene_name, "I": I_value, "expected_I": expected_I,
+                        "z_score": z_score, "p_value": float(p_all[u])})
+    adata.uns[key_added] = pd.DataFrame(results)
+
+    elapsed = time.time() - start_time
+    logger.info(f"Global Moran's I completed in {elapsed:.1f}s")
+    update_metadata(
+        adata,
+        function_name="morans_i",
+        parameters={
+            "genes": gene_names[:10] if len(gene_names) > 10 else gene_names,
+            "n_genes": n_genes,
+            "n_neighbors": n_neighbors,
+            "n_permutations": n_permutations,
+            "use_existing_graph": use_existing_graph,
+            "seed": seed,
+            "backend": "hip_gfx950",
+        },
+        outputs={"uns": key_added},
+    )
+    return adata
+
+
+# =============================================================================================
+# Global Lee's L (AC:991-1163)
+# =============================================================================================
+
+
+def _normalize_pairs(gene_pairs):
+    single = False
+    if isinstance(gene_pairs, tuple) and len(gene_pairs) == 2 and isinstance(gene_pairs[0], str):
+        gene_pairs = [gene_pairs]
+        single = True
+    return list(gene_pairs), single
+
+
+# device bytes allowed for one block of Lee permutations
+_LEE_PERM_BUDGET = 8 << 30
+
+
+def _lee_run(ctx, n_cells: int, pair_slots: np.ndarray, var: np.ndarray, n_permutations: int, seed_rng,
+             return_perms: bool = False):
+    """Global L + permutation counts for (x, y) slot pairs, drawing a fresh block of P permutations
+    per non-degenerate pair from ONE stream, in pair order (AC:1109-1148).  ``seed_rng`` is the 6-word
+    stream state, advanced in place."""
+    n_pairs = pair_slots.shape[0]
+    L = np.zeros(n_pairs)
+    cnt = np.zeros(n_pairs, dtype=np.int64)
+    Lp = np.zeros((n_pairs, n_permutations)) if return_perms else None
+    degenerate = ~((var[pair_slots[:, 0]] > 0) & (var[pair_slots[:, 1]] > 0))
+    per_block = max(1, int(_LEE_PERM_BUDGET // max(1, 4 * n_cells * max(n_permutations, 1))))
+    q = 0
+    while q < n_pairs:
+        q1 = min(n_pairs, q + per_block)
+        sel = np.arange(q, q1)
+        off = np.full(sel.size, -1, dtype=np.int64)
+        live = ~degenerate[sel]
+        off[live] = np.arange(int(live.sum())) * n_permutations
+        if n_permutations > 0 and live.any():
+            ctx.generate_permutations(seed_rng, n_cells, int(live.sum()) * n_permutations)
+        r = ctx.lee(pair_slots[sel, 0], pair_slots[sel, 1], off, n_permutations, return_perms=return_perms)
+        L[sel] = r["L"]
+        cnt[sel] = r["count_abs_ge"]
+        if return_perms:
+            Lp[sel] = r["L_perm"]
+        q = q1
+    return L, cnt, degenerate, Lp
+
+
+def lees_l(
+    adata,
+    gene_pairs: Union[Tuple[str, str], List[Tuple[str, str]]],
+    layer: Optional[str] = None,
+    spatial_key: str = "spatial",
+    n_neighbors: int = 6,
+    n_permutations: int = 199,
+    seed: int = 0,
+    *,
+    device: int = 0,
+) -> Union[dict, List[dict]]:
+    """Global Lee's L bivariate spatial association with permutation p-values (AC:991-1163).
+
+    Returns a dict ``{gene_x, gene_y, L, p_value}`` for a single pair, else a list of dicts.
+    ``L = sum_i z_x[i] * (W z_y)[i]`` on population-std z-scores; the permutation loop shuffles
+    ``z_y`` with the numpy-exact stream (one generator for all pairs, pairs with a zero-variance
+    gene draw nothing) and is evaluated on the GPU as ``sum_j (W^T z_x)[j] * z_y[perm[j]]``.
+    Arithmetic is fp64 (the reference inherits X's dtype).
+    """
+    start_time = time.time()
+    coords = _require_spatial(adata, spatial_key)
+    _check_counts(n_neighbors, n_permutations)
+    gene_pairs, single_pair = _normalize_pairs(gene_pairs)
+    all_genes = set(g for pair in gene_pairs for g in pair)
+    missing = all_genes - set(adata.var_names)
+    if missing:
+        raise ValueError(f"Genes not found in adata.var_names: {list(missing)}")
+    n_cells, n_pairs = adata.n_obs, len(gene_pairs)
+    logger.info(f"Computing Global Lee's L: {n_cells:,} cells, {n_pairs} pair(s), "
+                f"k={n_neighbors}, permutations={n_permutations}")
+
+    ctx = _lib.default_context(device)
+    _knn_weights_f32(ctx, coords, n_neighbors)
+    flat = [g for pair in gene_pairs for g in pair]
+    cols, where = _unique_columns(adata, flat)
+    ctx.set_expression(_expression(adata, layer), cols)
+    _, var = ctx.expr_stats()
+    pair_slots = where.reshape(-1, 2)
+    words = _lib.rng_state_words(np.random.default_rng(seed))
+    L, cnt, degenerate, _ = _lee_run(ctx, n_cells, pair_slots, var, n_permutations, words)
+
+    results = []
+    for q, (gene_x, gene_y) in enumerate(gene_pairs):
+        if degenerate[q]:
+            logger.warning(f"Gene pair ({gene_x}, {gene_y}) has zero variance gene - setting L to 0")
+            results.append({"gene_x": gene_x, "gene_y": gene_y, "L": 0.0, "p_value": 1.0})
+            continue
+        p_value = float((cnt[q] + 1) / (n_permutations + 1)) if n_permutations > 0 else 1.0
+        results.append({"gene_x": gene_x, "gene_y": gene_y, "L": float(L[q]), "p_value": p_value})
+
+    elapsed = time.time() - start_time
+    logger.info(f"Global Lee's L completed in {elapsed:.1f}s")
+    return results[0] if single_pair else results

@@ -1,0 +1,128 @@
+"""GPU: the AnnData-level drop-in functions vs the reference's golden outputs and the oracle."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden, make_adata, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_build_spatial_weights_golden():
+    from spatialcore_amd.spatial import build_spatial_weights
+
+    g = load_golden("ref_weights.npz")
+    for ci in range(int(g["n_cases"])):
+        coords = g[f"c{ci}_coords"]
+        ad = make_adata(coords, np.zeros((coords.shape[0], 1)))
+        W = build_spatial_weights(ad, n_neighbors=int(g[f"c{ci}_k"]), include_self=bool(g[f"c{ci}_include_self"]))
+        assert W.dtype == np.float32 and W.format == "csr" and W.has_sorted_indices
+        np.testing.assert_array_equal(W.indptr, g[f"c{ci}_W_indptr"])
+        np.testing.assert_array_equal(W.indices, g[f"c{ci}_W_indices"])
+        np.testing.assert_array_equal(W.data, g[f"c{ci}_W_data"])
+    with pytest.raises(ValueError, match="not found"):
+        build_spatial_weights(ad, spatial_key="nope")
+
+
+def test_morans_i_table_matches_oracle(oracle):
+    from spatialcore_amd.spatial import morans_i
+
+    coords, X = synth(10000, 50, 1, dtype=np.float32)           # BASELINE configs[0]
+    ad = make_adata(coords, X)
+    genes = [f"g{i}" for i in (3, 0, 17, 42, 8)]
+    out = morans_i(ad, genes=genes, n_neighbors=6, n_permutations=199, seed=0)
+    assert out is ad
+    df = ad.uns["morans_i"]
+    assert list(df.columns) == ["gene", "I", "expected_I", "z_score", "p_value"]
+    assert list(df["gene"]) == genes
+    tab = oracle.morans_i_reference_table(coords, X, [3, 0, 17, 42, 8], 6, 199, seed=0)
+    np.testing.assert_allclose(df["I"].values, tab["I"], rtol=1e-9)
+    np.testing.assert_allclose(df["z_score"].values, tab["z_score"], rtol=1e-9)
+    np.testing.assert_allclose(df["expected_I"].values, -1 / 9999, rtol=1e-15)
+    # p-values are (count+1)/(P+1): identical wherever no exact tie exists (DESIGN.md "Ties")
+    ties = (np.abs(tab["sims"] - tab["I"]) <= 1e-11 * np.abs(tab["I"])).sum(axis=0)
+    np.testing.assert_array_equal(df["p_value"].values[ties == 0], tab["p_value"][ties == 0])
+    assert (np.abs(df["p_value"].values - tab["p_value"]) <= ties / 200 + 1e-15).all()
+    # side effects of the reference: graph left in obsp, provenance appended
+    conn = ad.obsp["spatial_connectivities"]
+    assert conn.shape == (10000, 10000) and conn.nnz == 60000 and conn.dtype == np.float64
+    np.testing.assert_array_equal(conn.indices.reshape(-1, 6), oracle.knn_bruteforce(coords, 6))
+    assert ad.uns["spatialcore_metadata"]["operations"][-1]["function"] == "morans_i"
+    # use_existing_graph re-uses obsp; P = 0 falls back to the analytic p-value
+    morans_i(ad, genes=genes, n_neighbors=6, n_permutations=0, use_existing_graph=True, key_added="m0")
+    np.testing.assert_allclose(ad.uns["m0"]["I"].values, tab["I"], rtol=1e-9)
+    t0 = oracle.morans_i_reference_table(coords, X, [3, 0, 17, 42, 8], 6, 0, seed=0)
+    np.testing.assert_allclose(ad.uns["m0"]["p_value"].values, t0["p_value"], rtol=1e-6, atol=1e-300)
+
+
+def test_morans_i_errors_and_copy():
+    from spatialcore_amd.spatial import morans_i
+
+    coords, X = synth(500, 3, 2)
+    ad = make_adata(coords, X)
+    with pytest.raises(ValueError, match="n_neighbors must be >= 1"):
+        morans_i(ad, n_neighbors=0)
+    with pytest.raises(ValueError, match="n_permutations must be >= 0"):
+        morans_i(ad, n_permutations=-1)
+    with pytest.raises(ValueError, match="Genes not found"):
+        morans_i(ad, genes=["nope"])
+    with pytest.raises(ValueError, match="not found"):
+        morans_i(ad, spatial_key="xy")
+    out = morans_i(ad, genes="g1", n_permutations=5, copy=True)
+    assert out is not ad and "morans_i" in out.uns and "morans_i" not in ad.uns
+    assert len(out.uns["morans_i"]) == 1
+
+
+def test_lees_l_golden():
+    from spatialcore_amd.spatial import lees_l
+
+    g = load_golden("ref_lees_l.npz")
+    for ci in range(int(g["n_cases"])):
+        X = g[f"c{ci}_X"]
+        ad = make_adata(g[f"c{ci}_coords"], X)
+        pairs = [(f"g{a}", f"g{b}") for a, b in g[f"c{ci}_pairs"]]
+        res = lees_l(ad, gene_pairs=pairs, n_neighbors=int(g[f"c{ci}_k"]), n_permutations=int(g[f"c{ci}_P"]),
+                     seed=int(g[f"c{ci}_seed"]))
+        assert isinstance(res, list) and [(r["gene_x"], r["gene_y"]) for r in res] == pairs
+        tol = 1e-9 if X.dtype == np.float64 else 2e-5   # float32 goldens: the reference computed in float32
+        np.testing.assert_allclose([r["L"] for r in res], g[f"c{ci}_L"], rtol=tol, atol=tol)
+        np.testing.assert_array_equal([r["p_value"] for r in res], g[f"c{ci}_p"])
+        one = lees_l(ad, gene_pairs=pairs[0], n_neighbors=int(g[f"c{ci}_k"]), n_permutations=int(g[f"c{ci}_P"]),
+                     seed=int(g[f"c{ci}_seed"]))
+        assert isinstance(one, dict)
+        assert one["L"] == pytest.approx(float(g[f"c{ci}_single_L"]), rel=tol, abs=tol)
+        assert one["p_value"] == float(g[f"c{ci}_single_p"])
+
+
+def test_neighborhood_profile_golden():
+    from spatialcore_amd.spatial import compute_neighborhood_profile
+
+    g = load_golden("ref_profile.npz")
+    X = np.zeros((g["coords"].shape[0], 1))
+    for name in ("knn", "knn_raw", "radius", "radius_raw"):
+        ad = make_adata(g["coords"], X, labels=g["labels"])
+        kw = dict(method=str(g[f"{name}_method"]))
+        if kw["method"] == "knn":
+            kw["k"] = int(g[f"{name}_k"])
+        else:
+            kw["radius"] = float(g[f"{name}_radius"])
+        if f"{name}_normalize" in g:
+            kw["normalize"] = bool(g[f"{name}_normalize"])
+        err = str(g[f"{name}_error"])
+        if err:
+            with pytest.raises(ValueError) as ei:
+                compute_neighborhood_profile(ad, "cell_type", **kw)
+            assert str(ei.value) == err
+            continue
+        compute_neighborhood_profile(ad, "cell_type", **kw)
+        prof = ad.obsm["neighborhood_profile"]
+        assert prof.dtype == np.float32
+        np.testing.assert_array_equal(prof, g[f"{name}_profile"])
+        assert ad.uns["neighborhood_profile_celltypes"] == list(g[f"{name}_celltypes"])
+    ad = make_adata(g["coords"], X, labels=g["labels"])
+    with pytest.raises(ValueError, match="'radius' must be provided"):
+        compute_neighborhood_profile(ad, "cell_type", method="radius")
+    with pytest.raises(ValueError, match="k must be <"):
+        compute_neighborhood_profile(ad, "cell_type", k=10**6)
+    with pytest.raises(ValueError, match="empty neighborhood profiles"):
+        compute_neighborhood_profile(ad, "cell_type", method="radius", radius=1e-3)
