@@ -20,10 +20,11 @@ t = time.time(); ctx.knn(coords, K, fetch=False); ctx.sync(); print(f"knn N={N} 
 t = time.time(); ctx.knn(coords, K, fetch=False); ctx.sync(); print(f"knn again: {time.time()-t:.3f}s  kernel {ctx.kernel_time(_lib.K_KNN)}", flush=True)
 ctx.graph_from_knn(1.0 / K)
 t = time.time(); ctx.set_expression(X, np.arange(G)); print(f"expr upload: {time.time()-t:.3f}s", flush=True)
-t = time.time()
-perm = np.stack([rng.permutation(N).astype(np.int32) for _ in range(P)])
-print(f"host numpy perms ({P}): {time.time()-t:.2f}s", flush=True)
-ctx.set_permutations(perm)
+for rep in range(2):
+    w = _lib.rng_state_words(np.random.default_rng(0))
+    ctx.reset_timers()
+    t = time.time(); ctx.generate_permutations(w, N, P); dt = time.time() - t
+    print(f"device numpy-exact perms ({P} x {N}): wall {dt*1e3:.1f} ms, event {ctx.kernel_time(_lib.K_PERMGEN)[0]:.1f} ms", flush=True)
 for rep in range(3):
     ctx.reset_timers()
     t = time.time(); out = ctx.moran(P, return_sims=False); dt = time.time() - t
@@ -34,6 +35,4 @@ for rep in range(3):
     print(f"moran N={N} G={G} P={P}: wall {dt*1e3:.1f} ms; perm kernel {ms:.2f} ms over {cnt} launches "
           f"-> {alg/ms/1e9:.2f} TB/s algorithmic; lag {lag_ms:.2f} ms; "
           f"extrapolated P=1000 G=500: {ms/ (P*tiles) * 1000*32/1e3:.2f} s", flush=True)
-w = _lib.rng_state_words(np.random.default_rng(0))
-t = time.time(); ctx.generate_permutations(w, N, 8); print(f"host-exact perm gen: {(time.time()-t)/8*1e3:.1f} ms/perm", flush=True)
 print("mem GiB", ctx.device_mem() / 2**30)

@@ -1,0 +1,11 @@
+"""GPU box: time sc_perm_generate alone (for rocprofv3 --kernel-trace --stats)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from spatialcore_amd import _lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ctx = _lib.Context(0)
+for rep in range(2):
+    w = _lib.rng_state_words(np.random.default_rng(0))
+    t = time.time(); ctx.generate_permutations(w, N, P); print(f"perms {P} x {N}: {(time.time()-t)*1e3:.1f} ms", flush=True)

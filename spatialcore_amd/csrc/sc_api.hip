@@ -147,7 +147,7 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
-                    &c->lee_b, &c->lee_out, &c->lee_pairs};
+                    &c->lee_b, &c->lee_out, &c->lee_pairs, &c->pg_J, &c->pg_raw, &c->pg_out};
     for (DBuf *b : bufs) b->release(&c->mem);
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         for (auto &ev : c->timers[k].pending) {

@@ -93,6 +93,7 @@ struct sc_ctx {
     int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)
     DBuf perm;
     DBuf perm_flag;
+    DBuf pg_J, pg_raw, pg_out;  // device generator scratch: accepted j per step, raw 32-bit stream
 
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;

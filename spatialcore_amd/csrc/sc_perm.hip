@@ -9,7 +9,8 @@
 // `for i = n-1 .. 1: j = interval(i); swap(a[i], a[j])`.
 //
 // The stream is sequential (rejections make the draws per permutation data dependent).  The host
-// generator below is the simple exact form; the device table is filled from it.
+// generator below is the simple exact form (sc_perm_numpy_host); the device table is produced by
+// the parallel exact generator of sc_permgen.hip.
 #include <stdlib.h>
 #include <string.h>
 
@@ -158,40 +159,15 @@ extern "C" int sc_perm_generate(sc_ctx *c, uint64_t *state6, int64_t n, int64_t 
     SC_REQUIRE(c && state6, SC_ERR_INVALID, "sc_perm_generate: null pointer");
     SC_HIP(hipSetDevice(c->device));
     SC_TRY(perm_alloc(c, n, n_perm));
-    KernelTimerScope ts(c, SC_K_PERMGEN);
-    // host generation in blocks of rows, copied up while the next block is produced
-    const int64_t rows_per = (((int64_t)64 << 20) / (n * 4)) > 0 ? (((int64_t)64 << 20) / (n * 4)) : 1;
-    int32_t *stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    for (int b = 0; b < 2; ++b) {
-        SC_HIP(hipHostMalloc((void **)&stage[b], sizeof(int32_t) * (size_t)(rows_per * n), hipHostMallocDefault));
-        SC_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    {
+        KernelTimerScope ts(c, SC_K_PERMGEN);
+        SC_TRY(sc_perm_generate_device(c, state6, n, n_perm));
     }
-    Pcg64 g;
-    load(g, state6);
-    int rc = SC_OK;
-    int64_t blk = 0;
-    for (int64_t r0 = 0; r0 < n_perm && rc == SC_OK; r0 += rows_per, ++blk) {
-        int b = (int)(blk & 1);
-        int64_t rows = n_perm - r0 < rows_per ? n_perm - r0 : rows_per;
-        if (blk >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { rc = SC_ERR_HIP; break; }
-        for (int64_t r = 0; r < rows; ++r) shuffle_one(g, stage[b] + r * n, n);
-        if (perm_out) memcpy(perm_out + r0 * n, stage[b], sizeof(int32_t) * (size_t)(rows * n));
-        if (hipMemcpy2DAsync(c->perm.as<int32_t>() + r0 * c->p_stride, sizeof(int32_t) * (size_t)c->p_stride, stage[b],
-                             sizeof(int32_t) * (size_t)n, sizeof(int32_t) * (size_t)n, (size_t)rows,
-                             hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            hipEventRecord(done[b], c->stream) != hipSuccess) {
-            sc_set_error("sc_perm_generate: upload failed");
-            rc = SC_ERR_HIP;
-        }
-    }
-    (void)hipStreamSynchronize(c->stream);
-    for (int b = 0; b < 2; ++b) {
-        (void)hipHostFree(stage[b]);
-        (void)hipEventDestroy(done[b]);
-    }
-    if (rc != SC_OK) return rc;
-    store(g, state6);
     c->p_count = n_perm;
+    if (perm_out) {
+        SC_HIP(hipMemcpy2DAsync(perm_out, sizeof(int32_t) * (size_t)n, c->perm.p, sizeof(int32_t) * (size_t)c->p_stride,
+                                sizeof(int32_t) * (size_t)n, (size_t)n_perm, hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipStreamSynchronize(c->stream));
+    }
     return SC_OK;
 }

@@ -209,6 +209,35 @@ def _norm_sf_cdf(z: np.ndarray) -> np.ndarray:
     return p
 
 
+def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int) -> dict:
+    """Global Moran's I on operands already resident on the device (graph + expression tiles):
+    numpy-exact permutation table -> lag / permutation kernels -> p-value assembly as squidpy's
+    ``_p_value_calc`` / ``_analytic_pval`` do [upstream].  Shared by ``morans_i`` and ``bench.py``."""
+    if n_permutations > 0:
+        # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1
+        words = _lib.rng_state_words(np.random.default_rng(seed))
+        ctx.generate_permutations(words, n_cells, n_permutations)
+    out = ctx.moran(n_permutations, return_sims=False)
+    score = out["I"]
+    s0, s1, s2 = ctx.graph_moments()
+    n = float(n_cells)
+    expected_I = -1 / (n_cells - 1)
+    var_norm = (n * n * s1 - n * s2 + 3 * s0 * s0) / ((n - 1) * (n + 1) * s0 * s0) - (1.0 / (n - 1)) ** 2
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p_norm = _norm_sf_cdf((score - expected_I) / np.sqrt(var_norm))
+    res = {"I": score, "expected_I": expected_I, "var_norm": var_norm, "pval_norm": p_norm, "p_value": p_norm}
+    if n_permutations > 0:
+        large = out["count_ge"].copy()
+        flip = (n_permutations - large) < large
+        large[flip] = n_permutations - large[flip]
+        res["pval_sim"] = res["p_value"] = (large + 1) / (n_permutations + 1)
+        mean_sim = out["sim_sum"] / n_permutations
+        res["var_sim"] = np.maximum(out["sim_sumsq"] / n_permutations - mean_sim ** 2, 0.0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            res["pval_z_sim"] = _norm_sf_cdf((score - mean_sim) / np.sqrt(res["var_sim"]))
+    return res
+
+
 def morans_i(
     adata,
     genes: Optional[Union[str, List[str]]] = None,
@@ -254,26 +283,8 @@ def morans_i(
 
     cols, where = _unique_columns(adata, gene_names)
     ctx.set_expression(_expression(adata, layer), cols)
-    if n_permutations > 0:
-        # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1
-        words = _lib.rng_state_words(np.random.default_rng(seed))
-        ctx.generate_permutations(words, n_cells, n_permutations)
-    out = ctx.moran(n_permutations, return_sims=False)
-    score = out["I"]
-
-    # analytic moments under normality [upstream squidpy _analytic_pval]
-    s0, s1, s2 = ctx.graph_moments()
-    n = float(n_cells)
-    expected_I = -1 / (n_cells - 1)
-    var_norm = (n * n * s1 - n * s2 + 3 * s0 * s0) / ((n - 1) * (n + 1) * s0 * s0) - (1.0 / (n - 1)) ** 2
-    if n_permutations > 0:
-        large = out["count_ge"].copy()
-        flip = (n_permutations - large) < large
-        large[flip] = n_permutations - large[flip]
-        p_all = (large + 1) / (n_permutations + 1)
-    else:
-        with np.errstate(invalid="ignore", divide="ignore"):
-            p_all = _norm_sf_cdf((score - expected_I) / np.sqrt(var_norm))
+    res = _moran_resident(ctx, n_cells, n_permutations, seed)
+    score, p_all, var_norm, expected_I = res["I"], res["p_value"], res["var_norm"], res["expected_I"]
 
     results = []
     for gene_name, u in zip(gene_names, where):

@@ -77,6 +77,55 @@ def test_knn_degenerate_shapes(ctx, oracle):
         ctx.knn(np.array([[0.0, np.nan], [1.0, 1.0]]), 1)
 
 
+@pytest.mark.parametrize("seed,n,P", [(0, 10, 7), (1, 2, 9), (2, 1, 3), (3, 3, 40), (42, 257, 33), (7, 1000, 64),
+                                      (11, 4099, 21), (5, 65537, 9), (123456789, 200000, 12), (9, 1048577, 3)])
+def test_device_permutation_stream_is_numpy_exact(ctx, oracle, seed, n, P):
+    """sc_perm_generate (parallel device generator) == numpy's default_rng(seed).permutation(n) x P,
+    including the generator state it leaves behind."""
+    from spatialcore_amd._lib import rng_state_words
+
+    words = rng_state_words(np.random.default_rng(seed))
+    got = ctx.generate_permutations(words, n, P, fetch=True)
+    want, wwords = oracle.perm_table(seed, n, P)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(words, wwords)
+    # continue the same stream: a second block must pick up exactly where the first stopped
+    got2 = ctx.generate_permutations(words, n, 2, fetch=True)
+    want2, wwords2 = oracle.perm_table(wwords, n, 2)
+    np.testing.assert_array_equal(got2, want2)
+    np.testing.assert_array_equal(words, wwords2)
+
+
+def test_device_permutation_stream_golden_and_midword(ctx):
+    """numpy's own known answers (tests/golden/rng_kat.npz), incl. a generator that starts with a
+    buffered 32-bit half."""
+    kat = load_golden("rng_kat.npz")
+    for ci in range(int(kat["n_cases"])):
+        key = f"case{ci}_perms"
+        if key not in kat:
+            continue
+        n, reps = int(kat[f"case{ci}_n"]), kat[key].shape[0]
+        words = None
+        from spatialcore_amd._lib import rng_state_words
+        words = rng_state_words(np.random.default_rng(int(kat[f"case{ci}_seed"])))
+        np.testing.assert_array_equal(ctx.generate_permutations(words, n, reps, fetch=True), kat[key])
+        np.testing.assert_array_equal(words, kat[f"case{ci}_final_state"])
+    words = kat["mid_state"].copy()
+    assert int(words[4]) == 1
+    perms = ctx.generate_permutations(words, kat["mid_vals"].size, 3, fetch=True)
+    np.testing.assert_array_equal(kat["mid_vals"][perms], kat["mid_perm_vals"])
+
+
+def test_host_permutation_stream(oracle):
+    from spatialcore_amd import _lib
+
+    w = _lib.rng_state_words(np.random.default_rng(4))
+    got = _lib.perm_numpy_host(w, 5000, 4)
+    want, ww = oracle.perm_table(4, 5000, 4)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(w, ww)
+
+
 def test_reference_weights_golden(ctx):
     """build_spatial_weights goldens from the reference itself: indices bit-exact."""
     g = load_golden("ref_weights.npz")
