@@ -154,7 +154,8 @@ def main() -> None:
 
     perm_ms, perm_launches = ctx.kernel_time(_lib.K_MORAN_PERM)
     lag_ms, _ = ctx.kernel_time(_lib.K_LAG)
-    gen_ms, _ = ctx.kernel_time(_lib.K_PERMGEN)
+    scan_ms, _ = ctx.kernel_time(_lib.K_PERM_SCAN)
+    swap_ms, _ = ctx.kernel_time(_lib.K_PERM_SWAP)
     knn_ms, _ = ctx.kernel_time(_lib.K_KNN)
 
     if rank == 0:
@@ -162,7 +163,10 @@ def main() -> None:
         value = G * world * args.steps / elapsed
         # algorithmic bytes of ONE permutation-kernel launch (one 16-gene tile, all P permutations):
         # 16 B per (permutation, gene, cell) [z + gathered lag, fp64] + 4 B per (permutation, cell)
-        alg_bytes = P * 16 * n * 16.0 + P * n * 4.0
+        # -> per step: tiles x (P*16*n*16 + P*n*4); a launch covers one tile x one chunk of permutations
+        tiles = (G + 15) // 16
+        launches_per_step = max(perm_launches // max(args.steps, 1), 1)
+        alg_bytes = tiles * (P * 16 * n * 16.0 + P * n * 4.0) / launches_per_step
         avg_ms = perm_ms / max(perm_launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
         traffic = None
@@ -193,7 +197,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_moran_perm", "avg_launch_ms": avg_ms, "launches": perm_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "breakdown_ms_per_step": {"perm_table": gen_ms / args.steps, "moran_perm_kernel": perm_ms / args.steps,
+            "breakdown_ms_per_step": {"perm_scan_1wg_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
+                                      "moran_perm_kernel": perm_ms / args.steps,
                                       "lag_kernel": lag_ms / args.steps, "knn_kernel": knn_ms / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -8,4 +8,6 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = _lib.Context(0)
 for rep in range(2):
     w = _lib.rng_state_words(np.random.default_rng(0))
-    t = time.time(); ctx.generate_permutations(w, N, P); print(f"perms {P} x {N}: {(time.time()-t)*1e3:.1f} ms", flush=True)
+    ctx.reset_timers()
+    t = time.time(); ctx.generate_permutations(w, N, P); dt = (time.time() - t) * 1e3
+    print(f"perms {P} x {N}: {dt:.1f} ms  scan {ctx.kernel_time(_lib.K_PERM_SCAN)[0]:.1f} ms  swaps {ctx.kernel_time(_lib.K_PERM_SWAP)[0]:.1f} ms", flush=True)

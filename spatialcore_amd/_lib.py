@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libspatialcore_hip.so")
 
 SC_OK, SC_ERR_INVALID, SC_ERR_STATE, SC_ERR_HIP, SC_ERR_NOMEM, SC_ERR_EMPTY = 0, 1, 2, 3, 4, 5
 SC_F32, SC_F64 = 0, 1
-K_MORAN_PERM, K_LAG, K_KNN, K_PERMGEN, K_LEE_PERM = 0, 1, 2, 3, 4
+K_MORAN_PERM, K_LAG, K_KNN, K_PERMGEN, K_LEE_PERM, K_PERM_SCAN, K_PERM_SWAP = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/spatialcore_hip.h declares: (name, argtypes); restype is always int
 _P = c_void_p
@@ -48,6 +48,7 @@ SYMBOLS = {
     "sc_perm_generate": [_P, _P, c_int64, c_int64, _P],
     "sc_perm_set": [_P, _P, c_int64, c_int64],
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
+    "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
 }
@@ -286,6 +287,18 @@ class Context:
         ssum = np.zeros(G, dtype=np.float64) if n_perm > 0 else None
         ssq = np.zeros(G, dtype=np.float64) if n_perm > 0 else None
         _check(self._lib.sc_moran(self._h, int(n_perm), _ptr(I), _ptr(sims), _ptr(cnt), _ptr(ssum), _ptr(ssq)))
+        return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
+
+    def moran_seeded(self, words: np.ndarray, n_perm: int, return_sims: bool = True):
+        """sc_perm_generate + sc_moran, pipelined on the device; `words` is advanced in place."""
+        G = self._n_genes
+        I = np.empty(G, dtype=np.float64)
+        sims = np.empty((n_perm, G), dtype=np.float64) if return_sims else None
+        cnt = np.zeros(G, dtype=np.int64)
+        ssum = np.zeros(G, dtype=np.float64)
+        ssq = np.zeros(G, dtype=np.float64)
+        _check(self._lib.sc_moran_seeded(self._h, _ptr(words), int(n_perm), _ptr(I), _ptr(sims), _ptr(cnt),
+                                         _ptr(ssum), _ptr(ssq)))
         return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
 
     def lee(self, pair_x, pair_y, perm_offset, n_perm: int, return_perms: bool = False):

@@ -46,7 +46,7 @@ void DBuf::release(int64_t *acct)
     cap = 0;
 }
 
-KernelTimerScope::KernelTimerScope(sc_ctx *ctx, int kid) : c(ctx), id(kid)
+KernelTimerScope::KernelTimerScope(sc_ctx *ctx, int kid, hipStream_t on) : c(ctx), id(kid), s(on ? on : ctx->stream)
 {
     if (!c->timing) return;
     KTimer &t = c->timers[id];
@@ -60,13 +60,13 @@ KernelTimerScope::KernelTimerScope(sc_ctx *ctx, int kid) : c(ctx), id(kid)
             return;
         }
     }
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, s);
 }
 
 KernelTimerScope::~KernelTimerScope()
 {
     if (!a) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, s);
     KTimer &t = c->timers[id];
     t.pending.emplace_back(a, b);
     t.launches += 1;
@@ -75,6 +75,8 @@ KernelTimerScope::~KernelTimerScope()
 int sc_timer_collect(sc_ctx *c)
 {
     SC_HIP(hipStreamSynchronize(c->stream));
+    if (c->stream2) SC_HIP(hipStreamSynchronize(c->stream2));
+    if (c->stream3) SC_HIP(hipStreamSynchronize(c->stream3));
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         KTimer &t = c->timers[k];
         for (auto &ev : t.pending) {
@@ -147,7 +149,7 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
-                    &c->lee_b, &c->lee_out, &c->lee_pairs, &c->pg_J, &c->pg_raw, &c->pg_out};
+                    &c->lee_b, &c->lee_out, &c->lee_pairs, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_bits, &c->pg_enter, &c->pg_sblk};
     for (DBuf *b : bufs) b->release(&c->mem);
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         for (auto &ev : c->timers[k].pending) {
@@ -159,6 +161,8 @@ int sc_ctx_destroy(sc_ctx *c)
             (void)hipEventDestroy(ev.second);
         }
     }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SC_OK;

@@ -11,6 +11,7 @@
 #include "../../include/spatialcore_hip.h"
 
 #define SC_TILE 16  // genes per tile: one 128-byte fp64 row per cell and tile
+#define PERM_CHUNK 128  // permutations per pipeline stage (generator scan -> swaps -> scoring)
 
 void sc_set_error(const char *fmt, ...);
 
@@ -57,6 +58,8 @@ struct KTimer {
 struct sc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // fused permutation/Moran pipeline: rejection scan runs ahead here
+    hipStream_t stream3 = nullptr;  // ... and the Fisher-Yates swaps of the scanned chunk here
     int64_t mem = 0;  // bytes allocated through DBuf
     bool timing = true;
     KTimer timers[SC_K_COUNT_];
@@ -93,7 +96,7 @@ struct sc_ctx {
     int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)
     DBuf perm;
     DBuf perm_flag;
-    DBuf pg_J, pg_raw, pg_out;  // device generator scratch: accepted j per step, raw 32-bit stream
+    DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
 
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
@@ -103,10 +106,31 @@ struct sc_ctx {
 struct KernelTimerScope {
     sc_ctx *c;
     int id;
+    hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
-    KernelTimerScope(sc_ctx *ctx, int kid);
+    KernelTimerScope(sc_ctx *ctx, int kid, hipStream_t on = nullptr);
     ~KernelTimerScope();
 };
+
+// One numpy-exact permutation job on the device (sc_permgen.hip): begin -> {scan, swap} per chunk
+// of permutations -> finish.  Scan state lives on the device so chunks chain without host syncs.
+struct PermJob {
+    int64_t n = 0, n_perm = 0;
+    uint64_t h = 0;            // 1 if the generator starts with a buffered 32-bit half
+    uint64_t st_hi = 0, st_lo = 0, inc_hi = 0, inc_lo = 0;
+    uint32_t buffered = 0;
+    uint64_t total_steps = 0;
+    uint64_t hi = 0;           // raw indices [0, hi) hold stream draws
+    bool trivial = false;      // n == 1
+    double draws_per_perm = 0; // expectation
+    int64_t p_done = 0;        // permutations covered by the scan launches so far
+    int64_t chunk_no = 0;
+};
+int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);
+int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s);
+int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s);
+int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);
+int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm);
 
 int sc_timer_collect(sc_ctx *c);
 

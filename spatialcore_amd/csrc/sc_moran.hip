@@ -414,18 +414,18 @@ __global__ __launch_bounds__(256) void k_moran_perm(const double *__restrict__ Z
     }
 }
 
-// sims[p][g0 + slot] = scale[slot] * sum_s partial[s][p][slot]   (ascending s)
+// sims[p0 + p][g0 + slot] = scale[slot] * sum_s partial[s][p][slot]   (ascending s)
 __global__ __launch_bounds__(256) void k_moran_finalize(const double *__restrict__ partial,
                                                         const double *__restrict__ scale,
                                                         double *__restrict__ sims, int n_perm, int splits,
-                                                        int64_t n_genes, int64_t g0)
+                                                        int64_t n_genes, int64_t g0, int64_t p0)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int p = t >> 4, slot = t & 15;
     if (p >= n_perm || g0 + slot >= n_genes) return;
     double s = 0.0;
     for (int k = 0; k < splits; ++k) s += partial[((int64_t)k * n_perm + p) * SC_TILE + slot];
-    sims[(int64_t)p * n_genes + g0 + slot] = scale[slot] * s;
+    sims[(p0 + p) * n_genes + g0 + slot] = scale[slot] * s;
 }
 
 // per gene: I = scale * Inum; scale = n / s0 / z2
@@ -489,8 +489,7 @@ static int pick_splits(int64_t n, int n_perm_tiles, int64_t *cells_per_split)
     return (int)ceil_div64(n, cps);
 }
 
-extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_out, int64_t *count_ge_out,
-                        double *sim_sum_out, double *sim_sumsq_out)
+static int moran_check(sc_ctx *c, int64_t n_perm, const double *I_out)
 {
     SC_REQUIRE(c && I_out, SC_ERR_INVALID, "sc_moran: null pointer");
     SC_REQUIRE(n_perm >= 0 && n_perm <= (1 << 24), SC_ERR_INVALID, "sc_moran: n_perm=%lld out of range",
@@ -500,51 +499,69 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "sc_moran: no graph set");
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_INVALID, "sc_moran: graph has %lld rows but expression has %lld cells",
                (long long)c->g_n, (long long)c->e_n);
-    if (n_perm > 0) {
-        SC_REQUIRE(c->p_count >= n_perm, SC_ERR_STATE, "sc_moran: permutation table holds %lld rows, need %lld",
-                   (long long)c->p_count, (long long)n_perm);
-        SC_REQUIRE(c->p_n == c->e_n, SC_ERR_INVALID, "sc_moran: permutation length %lld != n_cells %lld",
-                   (long long)c->p_n, (long long)c->e_n);
-    }
-    const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
-    const size_t tile_elems = (size_t)n * SC_TILE;
+    return SC_OK;
+}
 
+// z = x - mean, lag = W z, I = n/s0 * sum z*lag / sum z^2 (device), sims buffer sized for n_perm
+static int moran_prepare(sc_ctx *c, int64_t n_perm)
+{
+    const int64_t n = c->e_n, T = c->e_tiles;
     SC_TRY(sc_graph_ensure_s0(c));
     SC_TRY(expr_center(c));
-    SC_TRY(c->Lag.ensure((size_t)T * tile_elems * sizeof(double), &c->mem));
+    SC_TRY(c->Lag.ensure((size_t)T * n * SC_TILE * sizeof(double), &c->mem));
     SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>()));
     SC_TRY(colsum<OP_MUL>(c, c->Z.as<double>(), c->Lag.as<double>(), c->g_Inum.as<double>(), 1.0));
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(T * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1), &c->mem));
     SC_TRY(c->g_I.ensure(sizeof(double) * (size_t)T * SC_TILE, &c->mem));
-    double *dI = c->g_I.as<double>();
     hipLaunchKernelGGL(k_moran_scale, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
-                       c->g_z2.as<double>(), c->g_Inum.as<double>(), c->g_scale.as<double>(), dI,
+                       c->g_z2.as<double>(), c->g_Inum.as<double>(), c->g_scale.as<double>(), c->g_I.as<double>(),
                        (double)n / c->s0, T * SC_TILE);
     SC_HIP(hipGetLastError());
-
     if (n_perm > 0) {
-        int ptiles = (int)ceil_div64(n_perm, MP_PERMS_PER_BLOCK);
+        // partial sums for one chunk of permutations (<= PERM_CHUNK, or all of them in the unfused call)
         int64_t cps = 0;
-        int splits = pick_splits(n, ptiles, &cps);
+        int splits = pick_splits(n, 1, &cps);  // upper bound on the split count
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * SC_TILE, &c->mem));
-        for (int64_t t = 0; t < T; ++t) {
-            {
-                KernelTimerScope ts(c, SC_K_MORAN_PERM);
-                hipLaunchKernelGGL(k_moran_perm, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
-                                   c->Z.as<double>() + t * tile_elems, c->Lag.as<double>() + t * tile_elems,
-                                   c->perm.as<int32_t>(), c->partial.as<double>(), n, c->p_stride, (int)n_perm,
-                                   cps);
-            }
-            hipLaunchKernelGGL(k_moran_finalize, dim3((unsigned)ceil_div64(n_perm * SC_TILE, 256)), dim3(256), 0,
-                               c->stream, c->partial.as<double>(), c->g_scale.as<double>() + t * SC_TILE,
-                               c->sims.as<double>(), (int)n_perm, splits, G, t * SC_TILE);
+    }
+    return SC_OK;
+}
+
+// score permutations [p0, p1) of the active table for every gene tile (on the context stream)
+static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1)
+{
+    const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
+    const size_t tile_elems = (size_t)n * SC_TILE;
+    const int cnt = (int)(p1 - p0);
+    if (cnt <= 0) return SC_OK;
+    const int ptiles = (int)ceil_div64(cnt, MP_PERMS_PER_BLOCK);
+    int64_t cps = 0;
+    const int splits = pick_splits(n, ptiles, &cps);
+    for (int64_t t = 0; t < T; ++t) {
+        {
+            KernelTimerScope ts(c, SC_K_MORAN_PERM);
+            hipLaunchKernelGGL(k_moran_perm, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
+                               c->Z.as<double>() + t * tile_elems, c->Lag.as<double>() + t * tile_elems,
+                               c->perm.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), n, c->p_stride,
+                               cnt, cps);
         }
-        SC_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_moran_finalize, dim3((unsigned)ceil_div64((int64_t)cnt * SC_TILE, 256)), dim3(256), 0,
+                           c->stream, c->partial.as<double>(), c->g_scale.as<double>() + t * SC_TILE,
+                           c->sims.as<double>(), cnt, splits, G, t * SC_TILE, p0);
+    }
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+static int moran_finish(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_out, int64_t *count_ge_out,
+                        double *sim_sum_out, double *sim_sumsq_out)
+{
+    const int64_t G = c->e_genes;
+    if (n_perm > 0) {
         SC_TRY(c->counts.ensure(sizeof(long long) * (size_t)G, &c->mem));
         SC_TRY(c->sim_sum.ensure(sizeof(double) * (size_t)G, &c->mem));
         SC_TRY(c->sim_sumsq.ensure(sizeof(double) * (size_t)G, &c->mem));
-        hipLaunchKernelGGL(k_moran_count, dim3((unsigned)G), dim3(256), 0, c->stream, c->sims.as<double>(), dI,
-                           (int)n_perm, G, c->counts.as<long long>(), c->sim_sum.as<double>(),
+        hipLaunchKernelGGL(k_moran_count, dim3((unsigned)G), dim3(256), 0, c->stream, c->sims.as<double>(),
+                           c->g_I.as<double>(), (int)n_perm, G, c->counts.as<long long>(), c->sim_sum.as<double>(),
                            c->sim_sumsq.as<double>());
         SC_HIP(hipGetLastError());
         if (sims_out)
@@ -560,9 +577,76 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
             SC_HIP(hipMemcpyAsync(sim_sumsq_out, c->sim_sumsq.p, sizeof(double) * (size_t)G,
                                   hipMemcpyDeviceToHost, c->stream));
     }
-    SC_HIP(hipMemcpyAsync(I_out, dI, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(I_out, c->g_I.p, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
+}
+
+extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_out, int64_t *count_ge_out,
+                        double *sim_sum_out, double *sim_sumsq_out)
+{
+    SC_TRY(moran_check(c, n_perm, I_out));
+    if (n_perm > 0) {
+        SC_REQUIRE(c->p_count >= n_perm, SC_ERR_STATE, "sc_moran: permutation table holds %lld rows, need %lld",
+                   (long long)c->p_count, (long long)n_perm);
+        SC_REQUIRE(c->p_n == c->e_n, SC_ERR_INVALID, "sc_moran: permutation length %lld != n_cells %lld",
+                   (long long)c->p_n, (long long)c->e_n);
+    }
+    SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
+    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1),
+                          &c->mem));
+    for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK)
+        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm));
+    return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+}
+
+extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
+                               int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+{
+    SC_REQUIRE(state6, SC_ERR_INVALID, "sc_moran_seeded: null state");
+    SC_TRY(moran_check(c, n_perm, I_out));
+    SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
+    const int64_t n = c->e_n;
+    SC_TRY(sc_perm_alloc(c, n, n_perm));
+    if (!c->stream2) SC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    // allocations first (hipMalloc synchronises the device), then the two streams run freely
+    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
+    PermJob job;
+    SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream2));
+    SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
+    const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK);
+    // stream2: scan(0) scan(1) ...      stream3: swaps(k) after scan(k)      stream: score(k) after swaps(k)
+    std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
+    int rc = SC_OK;
+    for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
+        const int64_t p0 = k * PERM_CHUNK, p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
+        hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
+        rc = permgen_scan_chunk(c, &job, p1, c->stream2);
+        if (rc == SC_OK && (hipEventCreateWithFlags(&scanned, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&swapped, hipEventDisableTiming) != hipSuccess ||
+                            hipEventRecord(scanned, c->stream2) != hipSuccess ||
+                            hipStreamWaitEvent(c->stream3, scanned, 0) != hipSuccess)) {
+            sc_set_error("sc_moran_seeded: event plumbing failed");
+            rc = SC_ERR_HIP;
+        }
+        if (rc == SC_OK) rc = permgen_swap_chunk(c, &job, p0, p1, c->stream3);
+        if (rc == SC_OK && (hipEventRecord(swapped, c->stream3) != hipSuccess ||
+                            hipStreamWaitEvent(c->stream, swapped, 0) != hipSuccess)) {
+            sc_set_error("sc_moran_seeded: event plumbing failed");
+            rc = SC_ERR_HIP;
+        }
+        if (rc == SC_OK) rc = moran_perm_range(c, p0, p1);
+    }
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream3);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (rc != SC_OK) return rc;
+    SC_TRY(permgen_finish(c, &job, state6));
+    c->p_count = n_perm;
+    return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
 // ------------------------------------------------------------------------------------------------

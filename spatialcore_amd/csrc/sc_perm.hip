@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_check_perm(const int32_t *__restrict__ 
     if (bad) atomicOr(flag, 1);
 }
 
-static int perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
+int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
 {
     SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL, SC_ERR_INVALID, "permutation length %lld out of range", (long long)n);
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "n_perm must be >= 1");
@@ -137,7 +137,7 @@ extern "C" int sc_perm_set(sc_ctx *c, const int32_t *perm, int64_t n, int64_t n_
 {
     SC_REQUIRE(c && perm, SC_ERR_INVALID, "sc_perm_set: null pointer");
     SC_HIP(hipSetDevice(c->device));
-    SC_TRY(perm_alloc(c, n, n_perm));
+    SC_TRY(sc_perm_alloc(c, n, n_perm));
     SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
     SC_HIP(hipMemsetAsync(c->perm.p, 0, sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), c->stream));
     SC_HIP(hipMemcpy2DAsync(c->perm.p, sizeof(int32_t) * (size_t)c->p_stride, perm, sizeof(int32_t) * (size_t)n,
@@ -158,7 +158,7 @@ extern "C" int sc_perm_generate(sc_ctx *c, uint64_t *state6, int64_t n, int64_t 
 {
     SC_REQUIRE(c && state6, SC_ERR_INVALID, "sc_perm_generate: null pointer");
     SC_HIP(hipSetDevice(c->device));
-    SC_TRY(perm_alloc(c, n, n_perm));
+    SC_TRY(sc_perm_alloc(c, n, n_perm));
     {
         KernelTimerScope ts(c, SC_K_PERMGEN);
         SC_TRY(sc_perm_generate_device(c, state6, n, n_perm));

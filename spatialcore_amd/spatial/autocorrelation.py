@@ -214,10 +214,12 @@ def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int) -> dict:
     numpy-exact permutation table -> lag / permutation kernels -> p-value assembly as squidpy's
     ``_p_value_calc`` / ``_analytic_pval`` do [upstream].  Shared by ``morans_i`` and ``bench.py``."""
     if n_permutations > 0:
-        # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1
+        # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1.  Table generation and
+        # scoring are pipelined on the device (sc_moran_seeded).
         words = _lib.rng_state_words(np.random.default_rng(seed))
-        ctx.generate_permutations(words, n_cells, n_permutations)
-    out = ctx.moran(n_permutations, return_sims=False)
+        out = ctx.moran_seeded(words, n_permutations, return_sims=False)
+    else:
+        out = ctx.moran(0, return_sims=False)
     score = out["I"]
     s0, s1, s2 = ctx.graph_moments()
     n = float(n_cells)

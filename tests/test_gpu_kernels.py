@@ -200,6 +200,29 @@ def test_moran_vs_oracle(ctx, oracle, n, G, k, P, dtype, sparse_x):
     np.testing.assert_allclose((s0, s1, s2), oracle.graph_moments(tab["graph"]), rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,G,P", [(5000, 20, 300), (1234, 3, 129), (800, 40, 1)])
+def test_moran_seeded_pipeline_equals_two_step(ctx, oracle, n, G, P):
+    """The fused generator/scoring pipeline (several 128-permutation chunks on two streams) gives
+    exactly what sc_perm_generate + sc_moran give, and leaves the same generator state."""
+    from spatialcore_amd._lib import rng_state_words
+
+    coords, X = synth(n, G, 31, dtype=np.float32)
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, np.arange(G))
+    w1 = rng_state_words(np.random.default_rng(7))
+    ctx.generate_permutations(w1, n, P)
+    two = ctx.moran(P)
+    w2 = rng_state_words(np.random.default_rng(7))
+    one = ctx.moran_seeded(w2, P)
+    np.testing.assert_array_equal(w1, w2)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    tab = oracle.morans_i_reference_table(coords, X, list(range(G)), 6, P, seed=7)
+    np.testing.assert_allclose(one["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
+    assert_counts_match(one["count_ge"], tab["sims"], tab["I"])
+
+
 def test_moran_gene_subset_and_uploaded_perms(ctx, oracle):
     coords, X = synth(4000, 12, 23, dtype=np.float32)
     cols = [7, 2, 11]
