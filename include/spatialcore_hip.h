@@ -148,6 +148,24 @@ int sc_lee(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, const int6
            int64_t n_pairs, int64_t n_perm, double *L_out, int64_t *count_abs_ge_out,
            double *L_perm_out);
 
+/* ---- N1: Local Moran's I ---------------------------------------------------------------------
+ * Replaces the batch body of local_morans_i (AC:845-896) for the loaded genes (= one batch), with the
+ * reference's float32 arithmetic: z = (float(x) - mean32) / sd32, lag = W32 @ z (row-sequential
+ * float32), I = z * lag, and per cell #{p : |Zs * (W @ Zs)| >= |I|} with Zs = z[perm_p], accumulated
+ * on the fly instead of the reference's (P, N, B) tensor + Python loops.  Permutations are rows
+ * [perm_row0, perm_row0 + n_perm) of the active table (the reference continues ONE stream across
+ * batches, AC:839,879).  Outputs are row-major [n_cells][n_genes]; zero_var_out[g] = 1 where the
+ * float32 sd is 0 (AC:825-830; the caller blanks those columns, AC:902-906). */
+int sc_local_moran(sc_ctx *ctx, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
+                   float *I_out, int32_t *count_out, uint8_t *zero_var_out);
+
+/* ---- N2: Local Lee's L -----------------------------------------------------------------------
+ * Replaces the per-pair body of lees_l_local (AC:1373-1413): population-std z-scores of the two
+ * loaded genes, lag = W z_y, L_local = z_x * lag, and (n_perm > 0) the per-cell count
+ * #{p : |float32(z_x[i] * (W z_y[perm_p])[i])| >= |L_local[i]|} over rows [perm_row0, +n_perm). */
+int sc_lee_local(sc_ctx *ctx, int32_t gene_x, int32_t gene_y, int64_t n_perm, int64_t perm_row0,
+                 double *zx_out, double *lag_out, double *L_local_out, int32_t *count_out);
+
 /* ---- A9: neighbourhood composition --------------------------------------------------------
  * Replaces the per-cell Python counting loops of NB:226-251 on the active graph's pattern:
  * counts_out[n][n_types] float32 = number of neighbours of each label.  Rows with no neighbour

@@ -197,7 +197,7 @@ def ref_lee_local(ac):
     for gi, (a, b) in enumerate(pairs):
         key = f"{a}_{b}"
         out[f"p{gi}_L_local"] = np.asarray(adata.obs[f"{key}_lees_l"].values)
-        out[f"p{gi}_quadrant"] = np.asarray(adata.obs[f"{key}_quadrant"].astype(str).values)
+        out[f"p{gi}_quadrant"] = np.asarray(adata.obs[f"{key}_quadrant"].astype(str).values, dtype="U2")
         out[f"p{gi}_pvalue"] = np.asarray(adata.obs[f"{key}_pvalue"].values)
         prm = adata.uns[f"{key}_lees_l_params"]
         out[f"p{gi}_global_L"] = np.array(prm["global_L"]); out[f"p{gi}_global_p"] = np.array(prm["global_pvalue"])

@@ -50,6 +50,8 @@ SYMBOLS = {
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
+    "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
+    "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
 }
 
@@ -310,6 +312,27 @@ class Context:
         Lp = np.empty((q, n_perm), dtype=np.float64) if return_perms else None
         _check(self._lib.sc_lee(self._h, _ptr(px), _ptr(py), _ptr(off), q, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
         return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
+
+    # ---- N1 / N2 ----------------------------------------------------------------------------
+    def local_moran(self, n_cells: int, n_perm: int, perm_row0: int = 0):
+        G = self._n_genes
+        z = np.empty((n_cells, G), dtype=np.float32)
+        lag = np.empty((n_cells, G), dtype=np.float32)
+        I = np.empty((n_cells, G), dtype=np.float32)
+        cnt = np.zeros((n_cells, G), dtype=np.int32) if n_perm > 0 else None
+        zero = np.zeros(G, dtype=np.uint8)
+        _check(self._lib.sc_local_moran(self._h, int(n_perm), int(perm_row0), _ptr(z), _ptr(lag), _ptr(I), _ptr(cnt),
+                                        _ptr(zero)))
+        return {"z": z, "lag": lag, "I": I, "count": cnt, "zero_var": zero.astype(bool)}
+
+    def lee_local(self, n_cells: int, gene_x: int, gene_y: int, n_perm: int = 0, perm_row0: int = 0):
+        zx = np.empty(n_cells, dtype=np.float64)
+        lag = np.empty(n_cells, dtype=np.float64)
+        L = np.empty(n_cells, dtype=np.float64)
+        cnt = np.zeros(n_cells, dtype=np.int32) if n_perm > 0 else None
+        _check(self._lib.sc_lee_local(self._h, int(gene_x), int(gene_y), int(n_perm), int(perm_row0), _ptr(zx),
+                                      _ptr(lag), _ptr(L), _ptr(cnt)))
+        return {"zx": zx, "lag": lag, "L_local": L, "count": cnt}
 
     # ---- A9 ---------------------------------------------------------------------------------
     def profile_counts(self, labels, n_types: int) -> np.ndarray:

@@ -88,6 +88,7 @@ struct sc_ctx {
 
     // ---- expression tiles ----
     int64_t e_n = 0, e_genes = 0, e_tiles = 0;
+    int e_dtype = SC_F64;  // dtype of the matrix the tiles were loaded from (the reference's float32 paths depend on it)
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene

@@ -75,6 +75,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     return SC_OK;
 }
 
+
 extern "C" int sc_expr_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t *indices,
                                const void *data, int dtype, int64_t n, int64_t n_vars,
                                const int32_t *gene_cols, int64_t n_genes)
@@ -85,6 +86,7 @@ extern "C" int sc_expr_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t *
     SC_HIP(hipSetDevice(c->device));
     c->e_n = 0;
     SC_TRY(expr_alloc(c, n, n_genes));
+    c->e_dtype = dtype;
     SC_REQUIRE(indptr[0] == 0, SC_ERR_INVALID, "sc_expr_set_csr: indptr[0] must be 0");
     for (int64_t i = 0; i < n; ++i)
         SC_REQUIRE(indptr[i + 1] >= indptr[i], SC_ERR_INVALID, "sc_expr_set_csr: indptr not monotone at row %lld",
@@ -152,6 +154,7 @@ extern "C" int sc_expr_set_dense(sc_ctx *c, const void *data, int dtype, int64_t
     SC_HIP(hipSetDevice(c->device));
     c->e_n = 0;
     SC_TRY(expr_alloc(c, n, n_genes));
+    c->e_dtype = dtype;
     for (int64_t g = 0; g < n_genes; ++g)
         SC_REQUIRE(gene_cols[g] >= 0 && gene_cols[g] < n_vars, SC_ERR_INVALID, "gene column %d out of range",
                    gene_cols[g]);
@@ -186,7 +189,7 @@ extern "C" int sc_expr_set_dense(sc_ctx *c, const void *data, int dtype, int64_t
 // per-gene column reductions over tiles (deterministic two-stage tree)
 // ------------------------------------------------------------------------------------------------
 
-enum { OP_ID = 0, OP_SQ = 1, OP_MUL = 2 };
+enum { OP_ID = 0, OP_SQ = 1, OP_MUL = 2, OP_NZ = 3 };
 
 #define RED_ROWS_PER_BLOCK 4096
 
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const double *__restrict
     for (int64_t r = r0 + rg; r < r1; r += 16) {
         double v = a[r * SC_TILE + slot];
         if (OP == OP_SQ) v = v * v;
+        if (OP == OP_NZ) v = (v != 0.0) ? 1.0 : 0.0;
         if (OP == OP_MUL) v = v * b[r * SC_TILE + slot];
         acc += v;
     }
@@ -797,5 +801,393 @@ extern "C" int sc_lee(sc_ctx *c, const int32_t *pair_x, const int32_t *pair_y, c
         if (L_perm_out)
             for (int64_t p = 0; p < n_perm; ++p) L_perm_out[q * n_perm + p] = do_perm ? host[(size_t)p] : 0.0;
     }
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// N1: Local Moran's I (AC:804-934) with the reference's float32 arithmetic
+//
+// The reference standardises in float32, takes lag = W32 @ Z32 with scipy's row-sequential float32
+// accumulation, and for every permutation recomputes Zs = Z[perm], lag_s = W @ Zs, I_perm = Zs * lag_s
+// into a (P, N, B) tensor before counting |I_perm| >= |I| per cell in a Python loop.  Here the count
+// is accumulated on the fly: thread = (cell, 4 genes of a 16-gene float tile), loop over permutations.
+// ------------------------------------------------------------------------------------------------
+
+// Z32[tile][cell][16] = (float(x) - mean32) / sd32  (two float32 roundings, AC:858); padded genes -> 0
+__global__ __launch_bounds__(256) void k_lm_standardize(const double *__restrict__ X, const float *__restrict__ mean32,
+                                                        const float *__restrict__ sd32, float *__restrict__ Z32,
+                                                        int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * SC_TILE) return;
+    int64_t tile = blockIdx.y;
+    int slot = (int)(t & 15);
+    float x = (float)X[tile * n * SC_TILE + t];
+    float sd = sd32[tile * SC_TILE + slot];
+    // IEEE float division via double (innocuous double rounding for 24-bit operands)
+    float z = (float)__ddiv_rn((double)__fsub_rn(x, mean32[tile * SC_TILE + slot]), (double)sd);
+    Z32[tile * n * SC_TILE + t] = z;
+}
+
+// ---- numpy's float summation, reproduced ---------------------------------------------------------
+// The reference takes the per-gene mean and E[x^2] with scipy's sparse `.mean(axis=0)` (AC:79-80,
+// 102-107): (data * T(1/n)) summed per CSC column by np.add.reduceat, i.e. first stored entry +
+// numpy's PAIRWISE sum of the rest (blocks of <= 128 with 8 strided accumulators, halving above
+// that with the split rounded down to a multiple of 8), in the matrix dtype T.  On count data the
+// per-cell |I_perm| >= |I| test is full of exact ties that are decided by the last bit of z, so the
+// float32 mean and sd must be THE SAME floats; a more accurate sum is not good enough.
+// One thread evaluates one (gene, statistic) stream; the recursion is an explicit stack.
+
+#define PWS_CHUNK 16
+#define PWS_THREADS 64
+
+template <typename T>
+struct NzStream {  // non-zero entries of one gene column of the dense tiles, in cell order
+    const double *col;
+    int64_t n, pos;
+    double *buf;  // this thread's LDS slice
+    int have, used;
+    T inv_n;
+    int square;
+    __device__ T next()
+    {
+        for (;;) {
+            if (used == have) {
+                have = 0;
+                used = 0;
+#pragma unroll
+                for (int k = 0; k < PWS_CHUNK; ++k) {
+                    double v = (pos + k < n) ? col[(pos + k) * SC_TILE] : 0.0;
+                    buf[k * PWS_THREADS] = v;
+                }
+                have = (int)((n - pos) < PWS_CHUNK ? (n - pos) : PWS_CHUNK);
+                pos += have;
+                if (have == 0) return (T)0;  // cannot happen: the caller never over-reads
+            }
+            const double v = buf[(used++) * PWS_THREADS];
+            if (v != 0.0) {
+                T x = (T)v;
+                if (square) x = x * x;
+                return x * inv_n;
+            }
+        }
+    }
+};
+
+template <typename T>
+__device__ T pw_leaf(NzStream<T> &it, uint32_t len)
+{
+    if (len < 8) {
+        T res = (T)(-0.0);
+        for (uint32_t i = 0; i < len; ++i) res += it.next();
+        return res;
+    }
+    T r0 = it.next(), r1 = it.next(), r2 = it.next(), r3 = it.next();
+    T r4 = it.next(), r5 = it.next(), r6 = it.next(), r7 = it.next();
+    uint32_t i = 8;
+    for (; i < len - (len % 8); i += 8) {
+        r0 += it.next(); r1 += it.next(); r2 += it.next(); r3 += it.next();
+        r4 += it.next(); r5 += it.next(); r6 += it.next(); r7 += it.next();
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < len; ++i) res += it.next();
+    return res;
+}
+
+template <typename T>
+__device__ T pw_sum(NzStream<T> &it, uint32_t n)
+{
+    uint32_t f_len[34];
+    T f_left[34];
+    unsigned char f_state[34];
+    int sp = 0;
+    T ret = (T)0;
+    f_len[0] = n; f_state[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int k = sp - 1;
+        const uint32_t len = f_len[k];
+        if (f_state[k] == 0) {
+            if (len <= 128) { ret = pw_leaf(it, len); --sp; continue; }
+            uint32_t n2 = len / 2; n2 -= n2 % 8;
+            f_state[k] = 1;
+            f_len[sp] = n2; f_state[sp] = 0; ++sp;
+        } else if (f_state[k] == 1) {
+            uint32_t n2 = len / 2; n2 -= n2 % 8;
+            f_left[k] = ret;
+            f_state[k] = 2;
+            f_len[sp] = len - n2; f_state[sp] = 0; ++sp;
+        } else {
+            ret = f_left[k] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+// out[2*g] = numpy mean, out[2*g+1] = numpy mean of squares, as T; nnz[g] = stored (non-zero) entries
+template <typename T>
+__global__ __launch_bounds__(PWS_THREADS) void k_np_colstats(const double *__restrict__ X, int64_t n,
+                                                             int64_t n_genes, const double *__restrict__ nnz,
+                                                             T *__restrict__ out)
+{
+    __shared__ double lds[PWS_CHUNK * PWS_THREADS];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = t >> 1;
+    if (g >= n_genes) return;
+    NzStream<T> it;
+    it.col = X + (g >> 4) * n * SC_TILE + (g & 15);
+    it.n = n; it.pos = 0; it.buf = lds + threadIdx.x; it.have = 0; it.used = 0;
+    it.inv_n = (T)(1.0 / (double)n);
+    it.square = (int)(t & 1);
+    const uint32_t cnt = (uint32_t)nnz[g];
+    T res = (T)0;
+    if (cnt >= 1) {
+        res = it.next();
+        if (cnt >= 2) res = res + pw_sum(it, cnt - 1);
+    }
+    out[t] = res;
+}
+
+// mean32 / sd32 exactly as AC:821-830: var = sqmean - mean^2 and sqrt in the matrix dtype T, then float32
+template <typename T>
+__global__ void k_lm_stats(const T *__restrict__ stats, float *__restrict__ mean32, float *__restrict__ sd32,
+                           unsigned char *__restrict__ zero, int64_t n_genes, int64_t total)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    if (g >= n_genes) { mean32[g] = 0.f; sd32[g] = 1.f; zero[g] = 1; return; }
+    const T m = stats[2 * g], q = stats[2 * g + 1];
+    const T var = q - m * m;
+    // sqrt in double, rounded once: correctly rounded for a float operand (53 >= 2*24 + 2 bits); the
+    // hardware v_sqrt_f32 alone is a 1-ulp approximation
+    const float sd = (float)__dsqrt_rn((double)var);
+    const bool z = (sd == 0.0f);
+    mean32[g] = (float)m;
+    sd32[g] = z ? 1.0f : sd;
+    zero[g] = z ? 1 : 0;
+}
+
+// observed: lag = W32 @ Z32 (row-sequential float32, mul and add rounded separately), I = Z * lag
+__global__ __launch_bounds__(256) void k_lm_observed(const long long *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices,
+                                                     const double *__restrict__ w, const float *__restrict__ Z32,
+                                                     float *__restrict__ Lag32, float *__restrict__ I32, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t >> 2;
+    int q = (int)(t & 3);
+    if (i >= n) return;
+    const float4 *Zt = reinterpret_cast<const float4 *>(Z32 + (int64_t)blockIdx.y * n * SC_TILE) + q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const float ww = (float)w[e];
+        const float4 z = Zt[(int64_t)indices[e] * 4];
+        s.x = __fadd_rn(s.x, __fmul_rn(ww, z.x)); s.y = __fadd_rn(s.y, __fmul_rn(ww, z.y));
+        s.z = __fadd_rn(s.z, __fmul_rn(ww, z.z)); s.w = __fadd_rn(s.w, __fmul_rn(ww, z.w));
+    }
+    const float4 zi = Zt[i * 4];
+    const int64_t o = (int64_t)blockIdx.y * n * 4 + i * 4 + q;
+    reinterpret_cast<float4 *>(Lag32)[o] = s;
+    reinterpret_cast<float4 *>(I32)[o] =
+        make_float4(__fmul_rn(zi.x, s.x), __fmul_rn(zi.y, s.y), __fmul_rn(zi.z, s.z), __fmul_rn(zi.w, s.w));
+}
+
+// count[i][g] += #{p : |Z[perm_p[i]] * sum_e w_e Z[perm_p[col_e]]| >= |I[i]|}
+__global__ __launch_bounds__(256) void k_lm_perm_count(const long long *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices,
+                                                       const double *__restrict__ w, const float *__restrict__ Z32,
+                                                       const float *__restrict__ I32,
+                                                       const int32_t *__restrict__ perm, int64_t pstride,
+                                                       int n_perm, int32_t *__restrict__ count, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t >> 2;
+    int q = (int)(t & 3);
+    if (i >= n) return;
+    const float4 *Zt = reinterpret_cast<const float4 *>(Z32 + (int64_t)blockIdx.y * n * SC_TILE) + q;
+    const int64_t o = (int64_t)blockIdx.y * n * 4 + i * 4 + q;
+    const float4 obs = reinterpret_cast<const float4 *>(I32)[o];
+    const float ax = fabsf(obs.x), ay = fabsf(obs.y), az = fabsf(obs.z), aw = fabsf(obs.w);
+    const long long e0 = indptr[i], e1 = indptr[i + 1];
+    int cx = 0, cy = 0, cz = 0, cw = 0;
+    for (int p = 0; p < n_perm; ++p) {
+        const int32_t *prow = perm + (int64_t)p * pstride;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long e = e0; e < e1; ++e) {
+            const float ww = (float)w[e];
+            const float4 z = Zt[(int64_t)prow[indices[e]] * 4];
+            s.x = __fadd_rn(s.x, __fmul_rn(ww, z.x)); s.y = __fadd_rn(s.y, __fmul_rn(ww, z.y));
+            s.z = __fadd_rn(s.z, __fmul_rn(ww, z.z)); s.w = __fadd_rn(s.w, __fmul_rn(ww, z.w));
+        }
+        const float4 zi = Zt[(int64_t)prow[i] * 4];
+        cx += fabsf(__fmul_rn(zi.x, s.x)) >= ax; cy += fabsf(__fmul_rn(zi.y, s.y)) >= ay;
+        cz += fabsf(__fmul_rn(zi.z, s.z)) >= az; cw += fabsf(__fmul_rn(zi.w, s.w)) >= aw;
+    }
+    reinterpret_cast<int4 *>(count)[o] = make_int4(cx, cy, cz, cw);
+}
+
+// tile layout [tile][cell][16] -> row-major [cell][n_genes]
+template <typename T>
+__global__ __launch_bounds__(256) void k_untile(const T *__restrict__ tiles, T *__restrict__ out, int64_t n,
+                                                int64_t n_genes)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_genes) return;
+    int64_t i = t / n_genes, g = t - i * n_genes;
+    out[t] = tiles[(g >> 4) * n * SC_TILE + i * SC_TILE + (g & 15)];
+}
+
+extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
+                              float *I_out, int32_t *count_out, uint8_t *zero_var_out)
+{
+    SC_REQUIRE(c && z_out && lag_out && I_out, SC_ERR_INVALID, "sc_local_moran: null pointer");
+    SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_local_moran: negative size");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran: graph missing or size mismatch");
+    if (n_perm > 0) {
+        SC_REQUIRE(count_out, SC_ERR_INVALID, "sc_local_moran: count_out required when n_perm > 0");
+        SC_REQUIRE(c->p_n == c->e_n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
+                   "sc_local_moran: needs permutation rows [%lld, %lld) of length %lld", (long long)perm_row0,
+                   (long long)(perm_row0 + n_perm), (long long)c->e_n);
+    }
+    const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
+    const size_t tile_f = (size_t)T * n * SC_TILE;
+    // per-gene mean and E[x^2] with numpy's own summation order, in the matrix dtype (see k_np_colstats)
+    SC_TRY(colsum<OP_NZ>(c, c->X.as<double>(), nullptr, c->g_Inum.as<double>(), 1.0));
+    SC_TRY(c->lee_out.ensure(sizeof(double) * 2 * (size_t)(T * SC_TILE), &c->mem));
+    {
+        const unsigned blocks = (unsigned)ceil_div64(2 * G, PWS_THREADS);
+        if (c->e_dtype == SC_F32)
+            hipLaunchKernelGGL(k_np_colstats<float>, dim3(blocks), dim3(PWS_THREADS), 0, c->stream, c->X.as<double>(),
+                               n, G, c->g_Inum.as<double>(), c->lee_out.as<float>());
+        else
+            hipLaunchKernelGGL(k_np_colstats<double>, dim3(blocks), dim3(PWS_THREADS), 0, c->stream,
+                               c->X.as<double>(), n, G, c->g_Inum.as<double>(), c->lee_out.as<double>());
+    }
+    // float work buffers: [mean32 | sd32] in g_scale (as float), zero flags in counts, Z32/Lag32/I32 in Z/Lag
+    SC_TRY(c->Z.ensure(tile_f * sizeof(double), &c->mem));    // Z32 (first half) + I32 (second half)
+    SC_TRY(c->Lag.ensure(tile_f * sizeof(double), &c->mem));  // Lag32 (first half) + counts (second half)
+    SC_TRY(c->counts.ensure((size_t)T * SC_TILE + 16, &c->mem));
+    float *mean32 = c->g_scale.as<float>(), *sd32 = mean32 + T * SC_TILE;
+    float *Z32 = c->Z.as<float>(), *I32 = Z32 + tile_f;
+    float *Lag32 = c->Lag.as<float>();
+    int32_t *cnt = reinterpret_cast<int32_t *>(Lag32 + tile_f);
+    unsigned char *zero = c->counts.as<unsigned char>();
+    if (c->e_dtype == SC_F32)
+        hipLaunchKernelGGL(k_lm_stats<float>, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
+                           c->lee_out.as<float>(), mean32, sd32, zero, G, T * SC_TILE);
+    else
+        hipLaunchKernelGGL(k_lm_stats<double>, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
+                           c->lee_out.as<double>(), mean32, sd32, zero, G, T * SC_TILE);
+    dim3 ge((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)T);
+    hipLaunchKernelGGL(k_lm_standardize, ge, dim3(256), 0, c->stream, c->X.as<double>(), mean32, sd32, Z32, n);
+    dim3 gc((unsigned)ceil_div64(n * 4, 256), (unsigned)T);
+    hipLaunchKernelGGL(k_lm_observed, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                       c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, Lag32, I32, n);
+    if (n_perm > 0) {
+        KernelTimerScope ts(c, SC_K_LEE_PERM);
+        hipLaunchKernelGGL(k_lm_perm_count, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, I32,
+                           c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, cnt, n);
+    }
+    SC_HIP(hipGetLastError());
+    // un-tile into row-major (cells x genes) staging and copy back
+    SC_TRY(c->lee_a.ensure(sizeof(float) * (size_t)n * (size_t)G, &c->mem));
+    unsigned gu = (unsigned)ceil_div64(n * G, 256);
+    struct { const float *src; float *dst; } outs[3] = {{Z32, z_out}, {Lag32, lag_out}, {I32, I_out}};
+    for (auto &o : outs) {
+        hipLaunchKernelGGL(k_untile<float>, dim3(gu), dim3(256), 0, c->stream, o.src, c->lee_a.as<float>(), n, G);
+        SC_HIP(hipMemcpyAsync(o.dst, c->lee_a.p, sizeof(float) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
+                              c->stream));
+    }
+    if (n_perm > 0) {
+        hipLaunchKernelGGL(k_untile<int32_t>, dim3(gu), dim3(256), 0, c->stream, cnt, c->lee_a.as<int32_t>(), n, G);
+        SC_HIP(hipMemcpyAsync(count_out, c->lee_a.p, sizeof(int32_t) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
+                              c->stream));
+    }
+    if (zero_var_out)
+        SC_HIP(hipMemcpyAsync(zero_var_out, zero, (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// N2: Local Lee's L for one pair (AC:1394-1413): z-scores, lag = W z_y, L_local = z_x * lag, and the
+// optional per-cell permutation count  #{p : |float32(z_x[i] * (W z_y[perm_p])[i])| >= |L_local[i]|}
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_lee_local_count(const long long *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices,
+                                                         const double *__restrict__ w, const double *__restrict__ zx,
+                                                         const double *__restrict__ zy,
+                                                         const double *__restrict__ Llocal,
+                                                         const int32_t *__restrict__ perm, int64_t pstride,
+                                                         int n_perm, int32_t *__restrict__ count, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long e0 = indptr[i], e1 = indptr[i + 1];
+    const double x = zx[i], obs = fabs(Llocal[i]);
+    int cnt = 0;
+    for (int p = 0; p < n_perm; ++p) {
+        const int32_t *prow = perm + (int64_t)p * pstride;
+        double s = 0.0;
+        for (long long e = e0; e < e1; ++e) s = __dadd_rn(s, __dmul_rn(w[e], zy[prow[indices[e]]]));
+        // the reference stores the permuted values in a float32 array before comparing (AC:1402,1408)
+        const double lp = (double)(float)__dmul_rn(x, s);
+        cnt += fabs(lp) >= obs;
+    }
+    count[i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_vec_mul(const double *__restrict__ a, const double *__restrict__ b,
+                                                 double *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __dmul_rn(a[i], b[i]);
+}
+
+extern "C" int sc_lee_local(sc_ctx *c, int32_t gene_x, int32_t gene_y, int64_t n_perm, int64_t perm_row0,
+                            double *zx_out, double *lag_out, double *L_local_out, int32_t *count_out)
+{
+    SC_REQUIRE(c && zx_out && lag_out && L_local_out, SC_ERR_INVALID, "sc_lee_local: null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_lee_local: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_lee_local: graph missing or size mismatch");
+    SC_REQUIRE(gene_x >= 0 && gene_x < c->e_genes && gene_y >= 0 && gene_y < c->e_genes, SC_ERR_INVALID,
+               "sc_lee_local: gene index outside the loaded set");
+    if (n_perm > 0) {
+        SC_REQUIRE(count_out, SC_ERR_INVALID, "sc_lee_local: count_out required when n_perm > 0");
+        SC_REQUIRE(c->p_n == c->e_n && perm_row0 >= 0 && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
+                   "sc_lee_local: needs permutation rows [%lld, %lld)", (long long)perm_row0,
+                   (long long)(perm_row0 + n_perm));
+    }
+    const int64_t n = c->e_n, T = c->e_tiles;
+    SC_TRY(expr_center(c));
+    hipLaunchKernelGGL(k_div_sd, dim3((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)T), dim3(256), 0, c->stream,
+                       c->Z.as<double>(), c->g_var.as<double>(), n);
+    SC_TRY(c->lee_a.ensure(sizeof(double) * (size_t)n * 5, &c->mem));
+    double *vx = c->lee_a.as<double>(), *vy = vx + n, *vlag = vx + 2 * n, *vL = vx + 3 * n;
+    int32_t *vcnt = reinterpret_cast<int32_t *>(vx + 4 * n);
+    unsigned gcol = (unsigned)ceil_div64(n, 256);
+    hipLaunchKernelGGL(k_extract_col, dim3(gcol), dim3(256), 0, c->stream, c->Z.as<double>(), n, (int64_t)gene_x, vx);
+    hipLaunchKernelGGL(k_extract_col, dim3(gcol), dim3(256), 0, c->stream, c->Z.as<double>(), n, (int64_t)gene_y, vy);
+    sc_launch_spmv_vec(c, c->g_indptr.as<int64_t>(), c->g_indices.as<int32_t>(), c->g_data.as<double>(), vy, vlag, n);
+    hipLaunchKernelGGL(k_vec_mul, dim3(gcol), dim3(256), 0, c->stream, vx, vlag, vL, n);
+    if (n_perm > 0) {
+        KernelTimerScope ts(c, SC_K_LEE_PERM);
+        hipLaunchKernelGGL(k_lee_local_count, dim3(gcol), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), vx, vy, vL,
+                           c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, vcnt, n);
+    }
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(zx_out, vx, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(lag_out, vlag, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(L_local_out, vL, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (n_perm > 0)
+        SC_HIP(hipMemcpyAsync(count_out, vcnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }

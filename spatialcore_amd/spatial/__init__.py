@@ -4,13 +4,17 @@
 from spatialcore_amd.spatial.autocorrelation import (
     build_spatial_weights,
     lees_l,
+    lees_l_local,
+    local_morans_i,
     morans_i,
 )
 from spatialcore_amd.spatial.neighborhoods import compute_neighborhood_profile
 
 __all__ = [
     "morans_i",
+    "local_morans_i",
     "lees_l",
+    "lees_l_local",
     "build_spatial_weights",
     "compute_neighborhood_profile",
 ]

@@ -414,3 +414,299 @@ def lees_l(
     elapsed = time.time() - start_time
     logger.info(f"Global Lee's L completed in {elapsed:.1f}s")
     return results[0] if single_pair else results
+
+
+# =============================================================================================
+# Local Moran's I (AC:656-983)
+# =============================================================================================
+
+
+def _bh_from_counts(counts: np.ndarray, n_permutations: int) -> np.ndarray:
+    """Benjamini-Hochberg adjusted p-values of one gene from its per-cell permutation counts.
+
+    Same numbers as ``_fdr_correction_bh`` on ``p = float32((count + 1) / (P + 1))`` (AC:132-164,
+    894-896) without sorting N values: p takes at most P + 1 levels, and after the reference's
+    cumulative minimum every cell of a level gets ``min over higher-or-equal levels of p * n / (last
+    rank of that level)`` -- evaluated here with the reference's own dtypes (float32 product,
+    float64 quotient, float32 store)."""
+    n = counts.size
+    hist = np.bincount(counts, minlength=n_permutations + 1)[: n_permutations + 1]
+    levels = ((np.arange(n_permutations + 1) + 1) / (n_permutations + 1)).astype(np.float32)
+    last_rank = np.cumsum(hist)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = (levels * np.float32(n)).astype(np.float64) / last_rank
+    a[hist == 0] = np.inf
+    a = np.minimum.accumulate(a[::-1])[::-1]
+    return np.clip(a, 0, 1).astype(np.float32)[counts]
+
+
+def local_morans_i(
+    adata,
+    genes: Optional[Union[str, List[str]]] = None,
+    layer: Optional[str] = None,
+    spatial_key: str = "spatial",
+    n_neighbors: int = 6,
+    n_permutations: int = 10,
+    fdr_correction: str = "fdr_bh",
+    alpha: float = 0.05,
+    seed: int = 0,
+    batch_size: int = 100,
+    key_added: str = "local_morans",
+    copy: bool = False,
+    *,
+    device: int = 0,
+):
+    """Local Moran's I (LISA) with per-cell permutation p-values, FDR and quadrants (AC:656-983).
+
+    Outputs as the reference: ``obsm[{key}_I|_z|_lag|_p|_p_adj]`` float32 ``(n_cells, n_genes)``,
+    ``obsm[{key}_quadrant]`` int8, ``uns[{key}_params]``.  Arithmetic follows the reference's float32
+    path; genes are processed in batches of ``batch_size`` and every batch draws its own
+    ``n_permutations`` permutations from ONE numpy-exact stream (AC:839-879).  The per-cell counts
+    are accumulated on the GPU instead of materialising the reference's ``(P, N, B)`` tensor.
+    """
+    start_time = time.time()
+    coords = _require_spatial(adata, spatial_key)
+    _check_counts(n_neighbors, n_permutations)
+    if fdr_correction not in ["bonferroni", "fdr_bh", "none"]:
+        raise ValueError(f"Invalid fdr_correction: '{fdr_correction}'. Must be 'bonferroni', 'fdr_bh', or 'none'.")
+    adata = adata.copy() if copy else adata
+    gene_names = _resolve_genes(adata, genes, "This may be slow and memory-intensive.")
+    n_cells, n_genes = adata.n_obs, len(gene_names)
+    gene_indices = np.array([adata.var_names.get_loc(g) for g in gene_names])
+    logger.info(f"Computing Local Moran's I: {n_cells:,} cells, {n_genes} genes, "
+                f"k={n_neighbors}, permutations={n_permutations}")
+
+    ctx = _lib.default_context(device)
+    _knn_weights_f32(ctx, coords, n_neighbors)
+    X = _expression(adata, layer)
+
+    local_I = np.zeros((n_cells, n_genes), dtype=np.float32)
+    z_values = np.zeros((n_cells, n_genes), dtype=np.float32)
+    lag_values = np.zeros((n_cells, n_genes), dtype=np.float32)
+    p_values = np.ones((n_cells, n_genes), dtype=np.float32)
+    counts = np.full((n_cells, n_genes), n_permutations, dtype=np.int32)
+    zero_var_mask = np.zeros(n_genes, dtype=bool)
+
+    words = _lib.rng_state_words(np.random.default_rng(seed))
+    n_batches = (n_genes + batch_size - 1) // batch_size
+    logger.info(f"Processing {n_genes} genes in {n_batches} batches")
+    for batch_idx in range(n_batches):
+        b0, b1 = batch_idx * batch_size, min((batch_idx + 1) * batch_size, n_genes)
+        logger.debug(f"Processing batch {batch_idx + 1}/{n_batches}")
+        cols, inv = np.unique(gene_indices[b0:b1], return_inverse=True)
+        ctx.set_expression(X, cols.astype(np.int32))
+        if n_permutations > 0:
+            ctx.generate_permutations(words, n_cells, n_permutations)  # continues the one stream
+        r = ctx.local_moran(n_cells, n_permutations)
+        z_values[:, b0:b1] = r["z"][:, inv]
+        lag_values[:, b0:b1] = r["lag"][:, inv]
+        local_I[:, b0:b1] = r["I"][:, inv]
+        zero_var_mask[b0:b1] = r["zero_var"][inv]
+        if n_permutations > 0:
+            counts[:, b0:b1] = r["count"][:, inv]
+            p_values[:, b0:b1] = ((r["count"][:, inv] + 1) / (n_permutations + 1)).astype(np.float32)
+
+    zero_variance_genes = [gene_names[i] for i in np.where(zero_var_mask)[0]]
+    if zero_var_mask.any():
+        logger.warning(f"{int(zero_var_mask.sum())} genes have zero variance and will be skipped: "
+                       f"{zero_variance_genes[:5]}")
+        local_I[:, zero_var_mask] = 0.0
+        z_values[:, zero_var_mask] = 0.0
+        lag_values[:, zero_var_mask] = 0.0
+        p_values[:, zero_var_mask] = 1.0
+        counts[:, zero_var_mask] = n_permutations
+
+    if n_permutations > 0:
+        logger.debug(f"Applying {fdr_correction} correction")
+        p_adj = np.ones_like(p_values)
+        for gene_idx in range(n_genes):
+            if fdr_correction == "fdr_bh":
+                p_adj[:, gene_idx] = _bh_from_counts(counts[:, gene_idx], n_permutations)
+            else:
+                p_adj[:, gene_idx] = _apply_fdr_correction(p_values[:, gene_idx], fdr_correction)
+        logger.debug("Classifying LISA quadrants (with significance filtering)")
+        quadrants = _classify_quadrants(z_values, lag_values, p_adj, alpha)
+    else:
+        logger.warning("n_permutations=0: Quadrants classified by z/lag signs only, "
+                       "without significance filtering. Consider n_permutations>=99 for p-values.")
+        p_adj = p_values
+        quadrants = _classify_quadrants(z_values, lag_values, p_values=None, alpha=alpha)
+
+    adata.obsm[f"{key_added}_I"] = local_I
+    adata.obsm[f"{key_added}_z"] = z_values
+    adata.obsm[f"{key_added}_lag"] = lag_values
+    adata.obsm[f"{key_added}_p"] = p_values
+    adata.obsm[f"{key_added}_p_adj"] = p_adj
+    adata.obsm[f"{key_added}_quadrant"] = quadrants
+
+    elapsed = time.time() - start_time
+    adata.uns[f"{key_added}_params"] = {
+        "genes": gene_names,
+        "n_neighbors": n_neighbors,
+        "n_permutations": n_permutations,
+        "fdr_correction": fdr_correction,
+        "alpha": alpha,
+        "n_cells": n_cells,
+        "n_genes": n_genes,
+        "seed": seed,
+        "computation_time_seconds": elapsed,
+        "zero_variance_genes": zero_variance_genes,
+    }
+    n_significant = (quadrants != 0).sum(axis=0)
+    logger.info(f"Local Moran's I completed in {elapsed:.1f}s. "
+                f"Significant cells per gene: min={n_significant.min()}, max={n_significant.max()}")
+    update_metadata(
+        adata,
+        function_name="local_morans_i",
+        parameters={
+            "genes": gene_names[:10] if len(gene_names) > 10 else gene_names,
+            "n_genes": n_genes,
+            "n_neighbors": n_neighbors,
+            "n_permutations": n_permutations,
+            "fdr_correction": fdr_correction,
+            "alpha": alpha,
+            "seed": seed,
+        },
+        outputs={
+            "obsm_I": f"{key_added}_I",
+            "obsm_z": f"{key_added}_z",
+            "obsm_lag": f"{key_added}_lag",
+            "obsm_p": f"{key_added}_p",
+            "obsm_p_adj": f"{key_added}_p_adj",
+            "obsm_quadrant": f"{key_added}_quadrant",
+            "uns_params": f"{key_added}_params",
+        },
+    )
+    return adata
+
+
+# =============================================================================================
+# Local Lee's L (AC:1171-1479)
+# =============================================================================================
+
+
+def lees_l_local(
+    adata,
+    gene_pairs: Optional[Union[Tuple[str, str], List[Tuple[str, str]]]] = None,
+    genes: Optional[List[str]] = None,
+    layer: Optional[str] = None,
+    spatial_key: str = "spatial",
+    n_neighbors: int = 6,
+    n_permutations: int = 199,
+    compute_cell_pvalues: bool = False,
+    significance_filter: bool = False,
+    alpha: float = 0.05,
+    seed: int = 0,
+    copy: bool = False,
+    *,
+    device: int = 0,
+):
+    """Local Lee's L per gene pair (AC:1171-1479): ``obs[{x}_{y}_lees_l]`` float32,
+    ``obs[{x}_{y}_quadrant]`` Categorical [NS, HH, LL, HL, LH], ``obs[{x}_{y}_pvalue]`` float32,
+    ``uns[{x}_{y}_lees_l_params]``.  One numpy-exact stream serves all pairs: P permutations for the
+    global p-value, then (``compute_cell_pvalues``) P more for the per-cell p-values."""
+    from itertools import combinations
+
+    start_time = time.time()
+    if gene_pairs is None and genes is None:
+        raise ValueError("Must provide either 'gene_pairs' or 'genes' parameter. "
+                         "Example: gene_pairs=('CD8A', 'GZMB') or genes=['CD8A', 'GZMB', 'FOXP3']")
+    coords = _require_spatial(adata, spatial_key)
+    _check_counts(n_neighbors, n_permutations)
+    if significance_filter and not compute_cell_pvalues:
+        raise ValueError("significance_filter=True requires compute_cell_pvalues=True")
+    if genes is not None:
+        n_all = len(genes) * (len(genes) - 1) // 2
+        logger.warning(f"All-pairs mode: {len(genes)} genes = {n_all} pairs. "
+                       "This may take a very long time for large gene sets. "
+                       "Consider using explicit gene_pairs for better performance.")
+        gene_pairs = list(combinations(genes, 2))
+    else:
+        gene_pairs, _ = _normalize_pairs(gene_pairs)
+    all_genes = list(dict.fromkeys(g for pair in gene_pairs for g in pair))
+    missing = set(all_genes) - set(adata.var_names)
+    if missing:
+        raise ValueError(f"Genes not found in adata.var_names: {list(missing)}")
+    adata = adata.copy() if copy else adata
+    n_cells, n_pairs = adata.n_obs, len(gene_pairs)
+    logger.info(f"Computing Local Lee's L: {n_cells:,} cells, {n_pairs} pair(s), "
+                f"k={n_neighbors}, permutations={n_permutations}")
+
+    ctx = _lib.default_context(device)
+    _knn_weights_f32(ctx, coords, n_neighbors)
+    cols, _ = _unique_columns(adata, all_genes)
+    slot = {g: i for i, g in enumerate(all_genes)}
+    ctx.set_expression(_expression(adata, layer), cols)
+    _, var = ctx.expr_stats()
+    zero_var_genes = {g for g in all_genes if not var[slot[g]] > 0}
+    if zero_var_genes:
+        logger.warning(f"Genes with zero variance: {zero_var_genes}")
+
+    words = _lib.rng_state_words(np.random.default_rng(seed))
+    categories = ["NS", "HH", "LL", "HL", "LH"]
+    for pair_idx, (gene_x, gene_y) in enumerate(gene_pairs):
+        logger.debug(f"Processing pair {pair_idx + 1}/{n_pairs}: {gene_x} vs {gene_y}")
+        key = f"{gene_x}_{gene_y}"
+        if gene_x in zero_var_genes or gene_y in zero_var_genes:
+            adata.obs[f"{key}_lees_l"] = np.zeros(n_cells, dtype=np.float32)
+            adata.obs[f"{key}_quadrant"] = pd.Categorical(["NS"] * n_cells, categories=categories)
+            adata.uns[f"{key}_lees_l_params"] = {"gene_x": gene_x, "gene_y": gene_y, "global_L": 0.0,
+                                                 "global_pvalue": 1.0, "n_neighbors": n_neighbors,
+                                                 "zero_variance": True}
+            continue
+        sx, sy = slot[gene_x], slot[gene_y]
+        cell_p = compute_cell_pvalues and n_permutations > 0
+        global_pvalue = 1.0
+        if n_permutations > 0:
+            # global block first, then the per-cell block, from the same stream (AC:1394-1408)
+            ctx.generate_permutations(words, n_cells, n_permutations * (2 if cell_p else 1))
+            g = ctx.lee([sx], [sy], [0], n_permutations)
+            global_pvalue = float((g["count_abs_ge"][0] + 1) / (n_permutations + 1))
+        else:
+            g = ctx.lee([sx], [sy], None, 0)
+            if compute_cell_pvalues:
+                logger.warning("compute_cell_pvalues=True but n_permutations=0; p-values will be 1.0")
+        L_global = float(g["L"][0])
+        loc = ctx.lee_local(n_cells, sx, sy, n_permutations if cell_p else 0, n_permutations if cell_p else 0)
+        p_values = np.ones(n_cells, dtype=np.float32)
+        if cell_p:
+            p_values = ((loc["count"] + 1) / (n_permutations + 1)).astype(np.float32)
+        quadrants = _classify_quadrants(loc["zx"], loc["lag"], p_values if significance_filter else None, alpha)
+        labels = np.array(categories)[quadrants]
+        adata.obs[f"{key}_lees_l"] = loc["L_local"].astype(np.float32)
+        adata.obs[f"{key}_quadrant"] = pd.Categorical(labels, categories=categories)
+        adata.obs[f"{key}_pvalue"] = p_values.astype(np.float32)
+        cnt = np.bincount(quadrants, minlength=5)
+        adata.uns[f"{key}_lees_l_params"] = {
+            "gene_x": gene_x,
+            "gene_y": gene_y,
+            "global_L": L_global,
+            "global_pvalue": global_pvalue,
+            "n_neighbors": n_neighbors,
+            "n_permutations": n_permutations,
+            "compute_cell_pvalues": compute_cell_pvalues,
+            "significance_filter": significance_filter,
+            "alpha": alpha,
+            "quadrant_counts": {lab: int(cnt[i]) for i, lab in enumerate(categories)},
+        }
+
+    elapsed = time.time() - start_time
+    logger.info(f"Local Lee's L completed in {elapsed:.1f}s for {n_pairs} pair(s)")
+    pair_keys = [f"{gx}_{gy}" for gx, gy in gene_pairs]
+    update_metadata(
+        adata,
+        function_name="lees_l_local",
+        parameters={
+            "gene_pairs": [(gx, gy) for gx, gy in gene_pairs[:10]],
+            "n_pairs": n_pairs,
+            "n_neighbors": n_neighbors,
+            "n_permutations": n_permutations,
+            "compute_cell_pvalues": compute_cell_pvalues,
+            "significance_filter": significance_filter,
+            "alpha": alpha,
+            "seed": seed,
+        },
+        outputs={"obs_keys": [f"{k}_lees_l" for k in pair_keys[:5]],
+                 "uns_keys": [f"{k}_lees_l_params" for k in pair_keys[:5]]},
+    )
+    return adata

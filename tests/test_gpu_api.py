@@ -126,3 +126,64 @@ def test_neighborhood_profile_golden():
         compute_neighborhood_profile(ad, "cell_type", k=10**6)
     with pytest.raises(ValueError, match="empty neighborhood profiles"):
         compute_neighborhood_profile(ad, "cell_type", method="radius", radius=1e-3)
+
+
+def test_local_morans_i_golden():
+    """Reference golden (float32 outputs of the reference's own local_morans_i): every array bit for
+    bit -- z, lag, I, per-cell p, adjusted p, quadrants.  (The float32 mean / sd are reproduced with
+    numpy's pairwise summation order, see k_np_colstats.)"""
+    from spatialcore_amd.spatial import local_morans_i
+
+    g = load_golden("ref_local_morans.npz")
+    for ci in range(int(g["n_cases"])):
+        X = g[f"c{ci}_X"]
+        for as_sparse in (False, True):
+            from scipy import sparse as sp
+            ad = make_adata(g[f"c{ci}_coords"], sp.csr_matrix(X) if as_sparse else X)
+            local_morans_i(ad, genes=[f"g{i}" for i in range(X.shape[1])], n_neighbors=int(g[f"c{ci}_k"]),
+                           n_permutations=int(g[f"c{ci}_P"]), fdr_correction=str(g[f"c{ci}_fdr"]),
+                           alpha=float(g[f"c{ci}_alpha"]), seed=int(g[f"c{ci}_seed"]), batch_size=int(g[f"c{ci}_batch"]))
+            for f in ("z", "lag", "I", "p", "p_adj", "quadrant"):
+                got = ad.obsm[f"local_morans_{f}"]
+                assert got.dtype == g[f"c{ci}_{f}"].dtype
+                np.testing.assert_array_equal(got, g[f"c{ci}_{f}"], err_msg=f"case {ci} field {f} sparse={as_sparse}")
+            assert list(ad.uns["local_morans_params"]["zero_variance_genes"]) == list(g[f"c{ci}_zero_variance_genes"])
+            assert ad.uns["spatialcore_metadata"]["operations"][-1]["function"] == "local_morans_i"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_local_morans_i_vs_oracle_larger(oracle, dtype):
+    from spatialcore_amd.spatial import local_morans_i
+
+    coords, X = synth(3000, 7, 9, dtype=dtype)
+    ad = make_adata(coords, X)
+    local_morans_i(ad, n_neighbors=6, n_permutations=29, seed=3, batch_size=4, fdr_correction="fdr_bh", alpha=0.4)
+    r = oracle.local_morans_i(coords, X, np.arange(7), 6, 29, 3, fdr="fdr_bh", alpha=0.4, batch_size=4)
+    for f in ("z", "lag", "I", "p", "p_adj", "quadrant"):
+        np.testing.assert_array_equal(ad.obsm[f"local_morans_{f}"], r[f], err_msg=f)
+    with pytest.raises(ValueError, match="Invalid fdr_correction"):
+        local_morans_i(ad, fdr_correction="holm")
+
+
+def test_lees_l_local_golden():
+    from spatialcore_amd.spatial import lees_l_local
+
+    g = load_golden("ref_lees_l_local.npz")
+    ad = make_adata(g["coords"], g["X"])
+    pairs = [(f"g{a}", f"g{b}") for a, b in g["pairs"]]
+    lees_l_local(ad, gene_pairs=pairs, n_neighbors=int(g["k"]), n_permutations=int(g["P"]),
+                 compute_cell_pvalues=True, significance_filter=True, alpha=float(g["alpha"]), seed=int(g["seed"]))
+    for gi, (a, b) in enumerate(pairs):
+        key = f"{a}_{b}"
+        np.testing.assert_allclose(ad.obs[f"{key}_lees_l"].values, g[f"p{gi}_L_local"], rtol=1e-6, atol=1e-7)
+        assert ad.obs[f"{key}_lees_l"].dtype == np.float32
+        np.testing.assert_array_equal(ad.obs[f"{key}_pvalue"].values, g[f"p{gi}_pvalue"])
+        np.testing.assert_array_equal(ad.obs[f"{key}_quadrant"].astype(str).values, g[f"p{gi}_quadrant"])
+        prm = ad.uns[f"{key}_lees_l_params"]
+        assert prm["global_L"] == pytest.approx(float(g[f"p{gi}_global_L"]), rel=1e-9)
+        assert prm["global_pvalue"] == float(g[f"p{gi}_global_p"])
+        assert [prm["quadrant_counts"][q] for q in ["NS", "HH", "LL", "HL", "LH"]] == list(g[f"p{gi}_quadrant_counts"])
+    with pytest.raises(ValueError, match="requires compute_cell_pvalues"):
+        lees_l_local(ad, gene_pairs=pairs, significance_filter=True)
+    with pytest.raises(ValueError, match="Must provide either"):
+        lees_l_local(ad)
