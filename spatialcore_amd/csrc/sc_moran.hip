@@ -619,12 +619,24 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     PermJob job;
     SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream2));
     SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
-    const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK);
+    // chunk schedule: a short first chunk so that scoring starts early, then PERM_CHUNK each
+    std::vector<int64_t> bounds;
+    bounds.push_back(0);
+    {
+        int64_t p = 0;
+        const int64_t first = n_perm > 2 * PERM_CHUNK ? PERM_CHUNK / 4 : PERM_CHUNK;
+        while (p < n_perm) {
+            int64_t step = (p == 0) ? first : (p == first && first < PERM_CHUNK ? PERM_CHUNK - first : PERM_CHUNK);
+            p = p + step < n_perm ? p + step : n_perm;
+            bounds.push_back(p);
+        }
+    }
+    const int64_t chunks = (int64_t)bounds.size() - 1;
     // stream2: scan(0) scan(1) ...      stream3: swaps(k) after scan(k)      stream: score(k) after swaps(k)
     std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
     int rc = SC_OK;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
-        const int64_t p0 = k * PERM_CHUNK, p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
+        const int64_t p0 = bounds[(size_t)k], p1 = bounds[(size_t)k + 1];
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
         rc = permgen_scan_chunk(c, &job, p1, c->stream2);
         if (rc == SC_OK && (hipEventCreateWithFlags(&scanned, hipEventDisableTiming) != hipSuccess ||

@@ -429,7 +429,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     SC_TRY(c->pg_enter.ensure(sizeof(uint32_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
     SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)n_blocks, &c->mem));
     // pg_out: [0..3] scan state, then one {first block, end block} pair per chunk for k_expand
-    const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK);
+    const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK) + 2;  // the fused pipeline splits its first chunk
     SC_TRY(c->pg_out.ensure(sizeof(unsigned long long) * (size_t)(4 + 2 * (chunks + 1)), &c->mem));
     job->chunk_no = 0;
     // A generator that starts with a buffered 32-bit half: that half is the first draw of the

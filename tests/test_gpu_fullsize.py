@@ -1,0 +1,102 @@
+"""GPU: BASELINE.json's full problem size (1M cells, k=15) through size-independent properties.
+
+The oracle cannot run the whole workload in seconds, so these tests use invariants of the domain:
+permutation-table validity + spot rows against the host generator, identity / inverse permutation,
+affine invariance of Moran's I, agreement of a slice with the oracle, kNN spot checks against a tree.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000
+K = 15
+
+
+@pytest.fixture(scope="module")
+def big():
+    from spatialcore_amd._lib import Context
+
+    rng = np.random.default_rng(42)
+    coords = rng.uniform(0, np.sqrt(N) * 10.0, (N, 2))
+    G = 24
+    lam = np.exp(rng.uniform(np.log(0.05), np.log(5.0), G))
+    X = rng.poisson(lam, (N, G)).astype(np.float32)
+    X[:, ::2] += (2.0 * (1 + np.sin(coords[:, :1] / 900.0))).astype(np.float32)   # spatially smooth genes
+    with Context(0) as ctx:
+        yield ctx, coords, X
+
+
+def test_knn_1m_spot_check_against_tree(big, oracle):
+    from scipy.spatial import cKDTree
+
+    ctx, coords, _ = big
+    idx = ctx.knn(coords, K)
+    assert idx.shape == (N, K) and idx.min() >= 0 and idx.max() < N
+    assert (idx != np.arange(N)[:, None]).all()                       # self excluded
+    rows = np.random.default_rng(0).choice(N, 3000, replace=False)
+    _, nb = cKDTree(coords).query(coords[rows], k=K + 1)
+    np.testing.assert_array_equal(idx[rows], nb[:, 1:])               # bit-exact on the sampled rows
+
+
+def test_permutation_table_1m(big, oracle):
+    from spatialcore_amd import _lib
+
+    ctx, _, _ = big
+    P = 40
+    w = _lib.rng_state_words(np.random.default_rng(0))
+    perms = ctx.generate_permutations(w, N, P, fetch=True)
+    # every row is a permutation of 0..N-1 (checksum of checksums: sum and sum of squares + sort of one row)
+    s1 = perms.astype(np.int64).sum(axis=1)
+    assert (s1 == N * (N - 1) // 2).all()
+    assert (np.sort(perms[P - 1]) == np.arange(N)).all()
+    # rows 0 and P-1 and the final generator state against the host generator (numpy-exact, tested on CPU)
+    wh = _lib.rng_state_words(np.random.default_rng(0))
+    host = _lib.perm_numpy_host(wh, N, P)
+    np.testing.assert_array_equal(perms[0], host[0])
+    np.testing.assert_array_equal(perms[P - 1], host[P - 1])
+    np.testing.assert_array_equal(w, wh)
+
+
+def test_moran_1m_invariants(big, oracle):
+    from spatialcore_amd import _lib
+
+    ctx, coords, X = big
+    G = X.shape[1]
+    ctx.knn(coords, K, fetch=False)
+    ctx.graph_from_knn(1.0 / K)
+    ctx.set_expression(X, np.arange(G))
+    P = 24
+    w = _lib.rng_state_words(np.random.default_rng(3))
+    out = ctx.moran_seeded(w, P)
+    assert np.isfinite(out["I"]).all() and (np.abs(out["I"]) < 1.0).all()
+    assert (out["I"][::2] > 0.05).all()                               # the smooth genes are autocorrelated
+    np.testing.assert_array_equal(out["count_ge"], (out["sims"] >= out["I"]).sum(axis=0))
+    # permutation null of the i.i.d. genes (odd columns): centred on E[I] = -1/(N-1) with sd ~ sqrt(var_norm).
+    # (For smooth genes the row-permutation null is wider: its spread follows var(lag), not var_norm.)
+    s0, s1, s2 = ctx.graph_moments()
+    var_norm = (N * N * s1 - N * s2 + 3 * s0 * s0) / ((N - 1.0) * (N + 1.0) * s0 * s0) - (1.0 / (N - 1)) ** 2
+    zs = (out["sims"][:, 1::2] - (-1.0 / (N - 1))) / np.sqrt(var_norm)
+    assert abs(zs.mean()) < 0.3 and 0.7 < zs.std() < 1.3
+    # identity permutation reproduces the observed statistic; a table row and its use are consistent
+    ident = np.arange(N, dtype=np.int32)[None, :]
+    ctx.set_permutations(ident)
+    same = ctx.moran(1)
+    np.testing.assert_allclose(same["sims"][0], same["I"], rtol=1e-12)
+    np.testing.assert_allclose(same["I"], out["I"], rtol=1e-13)
+    # affine invariance: I(a x + b) == I(x)
+    ctx.set_expression(3.0 * X.astype(np.float64) + 7.0, np.arange(G))
+    aff = ctx.moran(1)
+    np.testing.assert_allclose(aff["I"], out["I"], rtol=1e-9)
+    # a slice against the oracle: 2 genes, observed I and one permutation's statistic
+    ctx.set_expression(X, np.arange(G))
+    perm1 = np.random.default_rng(5).permutation(N).astype(np.int32)[None, :]
+    ctx.set_permutations(perm1)
+    got = ctx.moran(1)
+    nbr = ctx.knn(coords, K)
+    from scipy.sparse import csr_matrix
+    g = csr_matrix((np.full(N * K, 1.0 / K), nbr.reshape(-1), np.arange(0, N * K + 1, K)), shape=(N, N))
+    g.sort_indices()
+    vals = np.ascontiguousarray(X[:, :2].T, dtype=np.float64)
+    np.testing.assert_allclose(got["I"][:2], oracle.morans_i_scores(g, vals), rtol=1e-9)
+    np.testing.assert_allclose(got["sims"][0, :2], oracle.morans_i_sims_gather(g, vals, perm1)[0], rtol=1e-9)
