@@ -95,6 +95,9 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="testing only: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code path "
+                         "on a 1-GPU box; never a measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,9 +109,16 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = "cpu" if rehearse else "cuda"
 
     from spatialcore_amd import _lib
     from spatialcore_amd.spatial.autocorrelation import _moran_resident
@@ -126,7 +136,7 @@ def main() -> None:
         ctx.graph_from_knn(1.0 / k)
         res = _moran_resident(ctx, n, P, args.seed)
         if world > 1:
-            mine = torch.from_numpy(np.stack([res["I"], res["p_value"]])).cuda()
+            mine = torch.from_numpy(np.stack([res["I"], res["p_value"]])).to(dev)
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)           # the single RCCL collective: per-gene I and p
             gathered = torch.stack(parts).cpu().numpy()
@@ -148,7 +158,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -188,9 +198,10 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL on one GPU over gloo -- not a measurement)",
             "config": {"workload": f"{n} cells (uniform 2-D), {G} genes per GPU, k={k} kNN, "
-                                   f"{P} numpy-exact permutations, seed={args.seed} (BASELINE configs[1])",
+                                   f"{P} numpy-exact permutations, seed={args.seed}"
+                                   + (" (BASELINE configs[1])" if (n, G, P, k) == (1_000_000, 500, 1000, 15) else " (non-default size)"),
                        "cells": n, "genes_per_gpu": G, "genes_total": G * world, "k": k, "perms": P,
                        "parallelism": f"gene-shard x{world}, one all-gather of (I, p)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
