@@ -166,6 +166,17 @@ int sc_local_moran(sc_ctx *ctx, int64_t n_perm, int64_t perm_row0, float *z_out,
 int sc_lee_local(sc_ctx *ctx, int32_t gene_x, int32_t gene_y, int64_t n_perm, int64_t perm_row0,
                  double *zx_out, double *lag_out, double *L_local_out, int32_t *count_out);
 
+/* ---- N3: domain distances (reference src/spatialcore/spatial/distance.py) -----------------------
+ * sc_nearest_2d replaces cKDTree(target_coords).query(source_coords, k=1) (distance.py:222-232,
+ * 359-367): index (into the target array, lowest index on ties) and euclidean distance
+ * sqrt(fl(fl(dx*dx)+fl(dy*dy))) of the nearest target for every query point.
+ * sc_pairwise_2d replaces cdist(a, b).mean() / .min() (distance.py:269, 349, 397): LDS-tiled
+ * brute force over all |a| x |b| pairs. */
+int sc_nearest_2d(sc_ctx *ctx, const double *xy_targets, int64_t n_targets, const double *xy_queries,
+                  int64_t n_queries, int32_t *idx_out, double *dist_out);
+int sc_pairwise_2d(sc_ctx *ctx, const double *xy_a, int64_t n_a, const double *xy_b, int64_t n_b,
+                   double *mean_out, double *min_out);
+
 /* ---- A9: neighbourhood composition --------------------------------------------------------
  * Replaces the per-cell Python counting loops of NB:226-251 on the active graph's pattern:
  * counts_out[n][n_types] float32 = number of neighbours of each label.  Rows with no neighbour

@@ -53,6 +53,8 @@ def import_reference():
         sys.modules[name] = pkg
     ac = importlib.import_module("spatialcore.spatial.autocorrelation")
     nb = importlib.import_module("spatialcore.spatial.neighborhoods")
+    global DS
+    DS = importlib.import_module("spatialcore.spatial.distance")
     return ac, nb
 
 
@@ -267,6 +269,49 @@ def ref_profile(nb):
     print("ref_profile.npz written")
 
 
+def domain_fixture():
+    """Cells on a tie-free plane with blob-shaped 'domains' in two label columns (NaN = no domain)."""
+    rng = np.random.default_rng(77)
+    n = 1500
+    coords = rng.uniform(0, 1000, (n, 2))
+    centres_a = {"B_1": (200, 200), "B_2": (700, 300), "B_3": (450, 800)}
+    centres_b = {"T_1": (800, 800), "T_2": (150, 650)}
+    dom_a = np.full(n, None, dtype=object)
+    dom_b = np.full(n, None, dtype=object)
+    for name, (cx, cy) in centres_a.items():
+        dom_a[np.hypot(coords[:, 0] - cx, coords[:, 1] - cy) < 90] = name
+    for name, (cx, cy) in centres_b.items():
+        dom_b[np.hypot(coords[:, 0] - cx, coords[:, 1] - cy) < 120] = name
+    return coords, dom_a, dom_b
+
+
+def ref_distance():
+    coords, dom_a, dom_b = domain_fixture()
+    out = {"coords": coords, "dom_a": np.array([x or "" for x in dom_a]), "dom_b": np.array([x or "" for x in dom_b])}
+    cases = [("min_both", dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="minimum", output_mode="both")),
+             ("min_matrix", dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="minimum", output_mode="matrix")),
+             ("mean_both", dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="mean", output_mode="both")),
+             ("centroid_both", dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="centroid", output_mode="both")),
+             ("self_min", dict(source_domain_column="dom_a", target_domain_column="dom_a", distance_metric="minimum", output_mode="both")),
+             ("self_centroid", dict(source_domain_column="dom_a", target_domain_column="dom_a", distance_metric="centroid", output_mode="both")),
+             ("subset_min", dict(source_domain_column="dom_a", target_domain_column="dom_b", source_domain_subset=["B_1", "B_3"],
+                                 target_domain_subset=["T_2"], distance_metric="minimum", output_mode="both"))]
+    for name, kw in cases:
+        obs = pd.DataFrame({"dom_a": dom_a, "dom_b": dom_b}, index=pd.RangeIndex(len(coords)).astype(str))
+        adata = SimpleAnnData(np.zeros((len(coords), 1)), obs=obs, var_names=["g0"], obsm={"spatial": coords})
+        DS.calculate_domain_distances(adata, **kw)
+        if kw["output_mode"] in ("cell", "both"):
+            out[f"{name}_dist"] = adata.obs["distance_to_target"].values.astype(np.float64)
+            out[f"{name}_nearest"] = np.array([x if isinstance(x, str) else "" for x in adata.obs["nearest_target_domain"].values])
+        dd = adata.uns["domain_distances"]
+        m = DS.get_distance_matrix(adata)
+        out[f"{name}_matrix"] = m.values.astype(np.float64)
+        out[f"{name}_rows"] = np.array(list(m.index)); out[f"{name}_cols"] = np.array(list(m.columns))
+        out[f"{name}_summary"] = np.array([dd["summary_statistics"][k] for k in ("min_distance", "max_distance", "mean_distance", "median_distance")])
+    np.savez_compressed(os.path.join(OUT, "ref_distance.npz"), **out)
+    print("ref_distance.npz written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng_kats()
@@ -277,6 +322,7 @@ def main():
     ref_local_moran(ac)
     ref_fdr_quadrants(ac)
     ref_profile(nb)
+    ref_distance()
 
 
 if __name__ == "__main__":

@@ -52,6 +52,8 @@ SYMBOLS = {
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
     "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
+    "sc_nearest_2d": [_P, _P, c_int64, _P, c_int64, _P, _P],
+    "sc_pairwise_2d": [_P, _P, c_int64, _P, c_int64, POINTER(c_double), POINTER(c_double)],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
 }
 
@@ -333,6 +335,20 @@ class Context:
         _check(self._lib.sc_lee_local(self._h, int(gene_x), int(gene_y), int(n_perm), int(perm_row0), _ptr(zx),
                                       _ptr(lag), _ptr(L), _ptr(cnt)))
         return {"zx": zx, "lag": lag, "L_local": L, "count": cnt}
+
+    # ---- N3 ---------------------------------------------------------------------------------
+    def nearest(self, targets, queries):
+        t, q = _c(targets, np.float64), _c(queries, np.float64)
+        idx = np.empty(q.shape[0], dtype=np.int32)
+        dist = np.empty(q.shape[0], dtype=np.float64)
+        _check(self._lib.sc_nearest_2d(self._h, _ptr(t), t.shape[0], _ptr(q), q.shape[0], _ptr(idx), _ptr(dist)))
+        return dist, idx
+
+    def pairwise(self, a, b):
+        a, b = _c(a, np.float64), _c(b, np.float64)
+        mean, mn = c_double(0), c_double(0)
+        _check(self._lib.sc_pairwise_2d(self._h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], byref(mean), byref(mn)))
+        return mean.value, mn.value
 
     # ---- A9 ---------------------------------------------------------------------------------
     def profile_counts(self, labels, n_types: int) -> np.ndarray:

@@ -737,3 +737,159 @@ extern "C" int sc_profile_counts(sc_ctx *c, const int32_t *labels, int64_t n, in
     }
     return SC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// N3: domain distances (reference src/spatialcore/spatial/distance.py)
+// ------------------------------------------------------------------------------------------------
+
+// nearest target of every query: ring walk over the TARGET bin grid (queries may lie outside it).
+// Ties go to the lowest target index.  dist = sqrt(fl(fl(dx*dx)+fl(dy*dy))), as cKDTree.query / cdist.
+__global__ __launch_bounds__(256) void k_nearest(const double *__restrict__ sx, const double *__restrict__ sy,
+                                                 const int32_t *__restrict__ sid,
+                                                 const int32_t *__restrict__ bin_start,
+                                                 const double *__restrict__ qxy, int64_t n_q, double x0, double y0,
+                                                 double h, int nbx, int nby, int32_t *__restrict__ idx_out,
+                                                 double *__restrict__ dist_out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_q) return;
+    const double qx = qxy[2 * t], qy = qxy[2 * t + 1];
+    const double inv_h = 1.0 / h;
+    const int bx = bin_coord(qx, x0, inv_h, nbx), by = bin_coord(qy, y0, inv_h, nby);
+    double best = DBL_MAX;
+    int best_id = 0x7fffffff;
+    const int rmax = (nbx > nby ? nbx : nby);
+    const double slack = 1e-9 * h;
+    for (int r = 0; r <= rmax; ++r) {
+        const int ylo = by - r, yhi = by + r, xlo = bx - r, xhi = bx + r;
+        const int cxlo = xlo < 0 ? 0 : xlo, cxhi = xhi >= nbx ? nbx - 1 : xhi;
+        for (int yy = (ylo < 0 ? 0 : ylo); yy <= (yhi >= nby ? nby - 1 : yhi); ++yy) {
+            const bool full = (yy == ylo) || (yy == yhi);
+            for (int seg = 0; seg < (full ? 1 : 2); ++seg) {
+                int b0, b1;
+                if (full) { b0 = cxlo; b1 = cxhi; }
+                else if (seg == 0) { if (xlo < 0) continue; b0 = b1 = xlo; }
+                else { if (xhi >= nbx || r == 0) continue; b0 = b1 = xhi; }
+                const int s0 = bin_start[yy * nbx + b0], s1 = bin_start[yy * nbx + b1 + 1];
+                for (int s = s0; s < s1; ++s) {
+                    const double dx = qx - sx[s], dy = qy - sy[s];
+                    const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                    const int cid = sid[s];
+                    if (cand_better(d, cid, best, best_id)) { best = d; best_id = cid; }
+                }
+            }
+        }
+        const bool l_out = xlo <= 0, r_out = xhi >= nbx - 1, b_out = ylo <= 0, t_out = yhi >= nby - 1;
+        if (l_out && r_out && b_out && t_out) break;
+        double m = DBL_MAX;
+        if (!l_out) m = fmin(m, qx - (x0 + (double)xlo * h));
+        if (!r_out) m = fmin(m, (x0 + (double)(xhi + 1) * h) - qx);
+        if (!b_out) m = fmin(m, qy - (y0 + (double)ylo * h));
+        if (!t_out) m = fmin(m, (y0 + (double)(yhi + 1) * h) - qy);
+        m -= slack;
+        if (m > 0.0 && best < m * m) break;
+    }
+    idx_out[t] = best_id;
+    dist_out[t] = __dsqrt_rn(best);
+}
+
+extern "C" int sc_nearest_2d(sc_ctx *c, const double *xy_targets, int64_t n_targets, const double *xy_queries,
+                             int64_t n_queries, int32_t *idx_out, double *dist_out)
+{
+    SC_REQUIRE(c && xy_targets && xy_queries && idx_out && dist_out, SC_ERR_INVALID, "sc_nearest_2d: null pointer");
+    SC_REQUIRE(n_targets >= 1 && n_queries >= 1 && n_queries <= 0x7fffffffLL, SC_ERR_INVALID,
+               "sc_nearest_2d: need at least one target and one query");
+    SC_HIP(hipSetDevice(c->device));
+    c->knn_n = 0;
+    c->radius = -1.0;
+    SC_TRY(build_bins(c, xy_targets, n_targets, 4.0, 0.0));
+    for (int64_t i = 0; i < n_queries; ++i)
+        SC_REQUIRE(isfinite(xy_queries[2 * i]) && isfinite(xy_queries[2 * i + 1]), SC_ERR_INVALID,
+                   "query coordinate %lld is not finite", (long long)i);
+    SC_TRY(c->e_tmp_data.ensure(sizeof(double) * 2 * (size_t)n_queries, &c->mem));
+    SC_TRY(c->knn_idx.ensure(sizeof(int32_t) * (size_t)n_queries, &c->mem));
+    SC_TRY(c->knn_rd.ensure(sizeof(double) * (size_t)n_queries, &c->mem));
+    SC_HIP(hipMemcpyAsync(c->e_tmp_data.p, xy_queries, sizeof(double) * 2 * (size_t)n_queries, hipMemcpyHostToDevice,
+                          c->stream));
+    {
+        KernelTimerScope ts(c, SC_K_KNN);
+        hipLaunchKernelGGL(k_nearest, dim3((unsigned)ceil_div64(n_queries, 256)), dim3(256), 0, c->stream,
+                           c->sx.as<double>(), c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(),
+                           c->e_tmp_data.as<double>(), n_queries, c->gx0, c->gy0, c->gh, c->nbx, c->nby,
+                           c->knn_idx.as<int32_t>(), c->knn_rd.as<double>());
+    }
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * (size_t)n_queries, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(dist_out, c->knn_rd.p, sizeof(double) * (size_t)n_queries, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// brute-force pairwise euclidean distances between two point sets, LDS-tiled: block = 256 points of A
+// (one per thread, in registers) x the whole of B streamed through LDS in tiles of 1024 points.
+// partial[block] = {sum of distances, min distance} for the block's A points.
+#define PW_BTILE 1024
+
+__global__ __launch_bounds__(256) void k_pairwise(const double *__restrict__ a, int64_t n_a,
+                                                  const double *__restrict__ b, int64_t n_b,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double2 tile[PW_BTILE];
+    __shared__ double red_s[256], red_m[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n_a;
+    const double ax = live ? a[2 * i] : 0.0, ay = live ? a[2 * i + 1] : 0.0;
+    double sum = 0.0, mn = DBL_MAX;
+    for (int64_t j0 = 0; j0 < n_b; j0 += PW_BTILE) {
+        const int cnt = (int)(n_b - j0 < PW_BTILE ? n_b - j0 : PW_BTILE);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) tile[k] = reinterpret_cast<const double2 *>(b)[j0 + k];
+        __syncthreads();
+        if (live) {
+            for (int k = 0; k < cnt; ++k) {
+                const double dx = ax - tile[k].x, dy = ay - tile[k].y;
+                const double d = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+                sum += d;
+                mn = d < mn ? d : mn;
+            }
+        }
+    }
+    red_s[threadIdx.x] = sum;
+    red_m[threadIdx.x] = mn;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red_s[threadIdx.x] += red_s[threadIdx.x + s];
+            red_m[threadIdx.x] = red_m[threadIdx.x + s] < red_m[threadIdx.x] ? red_m[threadIdx.x + s] : red_m[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = red_s[0];
+        partial[2 * blockIdx.x + 1] = red_m[0];
+    }
+}
+
+extern "C" int sc_pairwise_2d(sc_ctx *c, const double *xy_a, int64_t n_a, const double *xy_b, int64_t n_b,
+                              double *mean_out, double *min_out)
+{
+    SC_REQUIRE(c && xy_a && xy_b, SC_ERR_INVALID, "sc_pairwise_2d: null pointer");
+    SC_REQUIRE(n_a >= 1 && n_b >= 1, SC_ERR_INVALID, "sc_pairwise_2d: empty point set");
+    SC_HIP(hipSetDevice(c->device));
+    const int blocks = (int)ceil_div64(n_a, 256);
+    SC_TRY(c->e_tmp_data.ensure(sizeof(double) * 2 * (size_t)(n_a + n_b), &c->mem));
+    SC_TRY(c->red_tmp.ensure(sizeof(double) * 2 * (size_t)blocks, &c->mem));
+    double *da = c->e_tmp_data.as<double>(), *db = da + 2 * n_a;
+    SC_HIP(hipMemcpyAsync(da, xy_a, sizeof(double) * 2 * (size_t)n_a, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(db, xy_b, sizeof(double) * 2 * (size_t)n_b, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pairwise, dim3(blocks), dim3(256), 0, c->stream, da, n_a, db, n_b, c->red_tmp.as<double>());
+    SC_HIP(hipGetLastError());
+    std::vector<double> h((size_t)blocks * 2);
+    SC_HIP(hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    double s = 0.0, m = DBL_MAX;
+    for (int k = 0; k < blocks; ++k) { s += h[2 * k]; m = h[2 * k + 1] < m ? h[2 * k + 1] : m; }
+    if (mean_out) *mean_out = s / ((double)n_a * (double)n_b);
+    if (min_out) *min_out = m;
+    return SC_OK;
+}

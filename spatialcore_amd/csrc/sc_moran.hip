@@ -616,9 +616,6 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     // allocations first (hipMalloc synchronises the device), then the two streams run freely
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
-    PermJob job;
-    SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream2));
-    SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
     // chunk schedule: a short first chunk so that scoring starts early, then PERM_CHUNK each
     std::vector<int64_t> bounds;
     bounds.push_back(0);
@@ -634,11 +631,12 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     const int64_t chunks = (int64_t)bounds.size() - 1;
     // stream2: scan(0) scan(1) ...      stream3: swaps(k) after scan(k)      stream: score(k) after swaps(k)
     std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
-    int rc = SC_OK;
+    PermJob job;
+    int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
+    // the whole generator side is enqueued first: it depends on nothing else and is the longest chain
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
-        const int64_t p0 = bounds[(size_t)k], p1 = bounds[(size_t)k + 1];
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
-        rc = permgen_scan_chunk(c, &job, p1, c->stream2);
+        rc = permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2);
         if (rc == SC_OK && (hipEventCreateWithFlags(&scanned, hipEventDisableTiming) != hipSuccess ||
                             hipEventCreateWithFlags(&swapped, hipEventDisableTiming) != hipSuccess ||
                             hipEventRecord(scanned, c->stream2) != hipSuccess ||
@@ -646,13 +644,20 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK) rc = permgen_swap_chunk(c, &job, p0, p1, c->stream3);
-        if (rc == SC_OK && (hipEventRecord(swapped, c->stream3) != hipSuccess ||
-                            hipStreamWaitEvent(c->stream, swapped, 0) != hipSuccess)) {
+        if (rc == SC_OK) rc = permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], c->stream3);
+        if (rc == SC_OK && hipEventRecord(swapped, c->stream3) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK) rc = moran_perm_range(c, p0, p1);
+    }
+    // observed statistic, lag, graph moments (host-blocking in places) overlap the first scan chunk
+    if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
+    for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
+        if (hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
+            sc_set_error("sc_moran_seeded: event plumbing failed");
+            rc = SC_ERR_HIP;
+        }
+        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1]);
     }
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);

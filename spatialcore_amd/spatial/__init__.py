@@ -8,6 +8,7 @@ from spatialcore_amd.spatial.autocorrelation import (
     local_morans_i,
     morans_i,
 )
+from spatialcore_amd.spatial.distance import calculate_domain_distances, get_distance_matrix
 from spatialcore_amd.spatial.neighborhoods import compute_neighborhood_profile
 
 __all__ = [
@@ -17,4 +18,6 @@ __all__ = [
     "lees_l_local",
     "build_spatial_weights",
     "compute_neighborhood_profile",
+    "calculate_domain_distances",
+    "get_distance_matrix",
 ]

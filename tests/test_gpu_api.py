@@ -187,3 +187,61 @@ def test_lees_l_local_golden():
         lees_l_local(ad, gene_pairs=pairs, significance_filter=True)
     with pytest.raises(ValueError, match="Must provide either"):
         lees_l_local(ad)
+
+
+def _domain_adata(g):
+    import pandas as pd
+    from spatialcore_amd import SimpleAnnData
+
+    coords = g["coords"]
+    obs = pd.DataFrame({"dom_a": [x if x else None for x in g["dom_a"]], "dom_b": [x if x else None for x in g["dom_b"]]},
+                       index=pd.RangeIndex(len(coords)).astype(str))
+    return SimpleAnnData(np.zeros((len(coords), 1)), obs=obs, var_names=["g0"], obsm={"spatial": coords})
+
+
+def test_calculate_domain_distances_golden():
+    """Goldens from the reference's own calculate_domain_distances / get_distance_matrix."""
+    from spatialcore_amd.spatial import calculate_domain_distances, get_distance_matrix
+
+    g = load_golden("ref_distance.npz")
+    cases = {
+        "min_both": dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="minimum", output_mode="both"),
+        "min_matrix": dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="minimum", output_mode="matrix"),
+        "mean_both": dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="mean", output_mode="both"),
+        "centroid_both": dict(source_domain_column="dom_a", target_domain_column="dom_b", distance_metric="centroid", output_mode="both"),
+        "self_min": dict(source_domain_column="dom_a", target_domain_column="dom_a", distance_metric="minimum", output_mode="both"),
+        "self_centroid": dict(source_domain_column="dom_a", target_domain_column="dom_a", distance_metric="centroid", output_mode="both"),
+        "subset_min": dict(source_domain_column="dom_a", target_domain_column="dom_b", source_domain_subset=["B_1", "B_3"],
+                           target_domain_subset=["T_2"], distance_metric="minimum", output_mode="both"),
+    }
+    for name, kw in cases.items():
+        ad = _domain_adata(g)
+        calculate_domain_distances(ad, **kw)
+        m = get_distance_matrix(ad)
+        assert list(m.index) == list(g[f"{name}_rows"]) and list(m.columns) == list(g[f"{name}_cols"]), name
+        exact = kw["distance_metric"] == "minimum"
+        if exact:   # min of sqrt(fl(dx^2)+fl(dy^2)): same floats as cKDTree / cdist
+            np.testing.assert_array_equal(m.values.astype(float), g[f"{name}_matrix"], err_msg=name)
+        else:       # mean: summation order; centroid: identical numpy means
+            np.testing.assert_allclose(m.values.astype(float), g[f"{name}_matrix"], rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose([ad.uns["domain_distances"]["summary_statistics"][k] for k in
+                                    ("min_distance", "max_distance", "mean_distance", "median_distance")],
+                                   g[f"{name}_summary"], rtol=1e-12)
+        if kw["output_mode"] in ("cell", "both"):
+            d = ad.obs["distance_to_target"].values.astype(float)
+            if kw["distance_metric"] == "centroid":
+                np.testing.assert_allclose(d, g[f"{name}_dist"], rtol=1e-14, equal_nan=True, err_msg=name)
+            else:
+                np.testing.assert_array_equal(d, g[f"{name}_dist"], err_msg=name)
+            near = np.array([x if isinstance(x, str) else "" for x in ad.obs["nearest_target_domain"].values])
+            np.testing.assert_array_equal(near, g[f"{name}_nearest"], err_msg=name)
+        assert ad.uns["spatialcore_metadata"]["operations"][-1]["function"] == "calculate_domain_distances"
+    ad = _domain_adata(g)
+    with pytest.raises(ValueError, match="Invalid distance_metric"):
+        calculate_domain_distances(ad, "dom_a", "dom_b", distance_metric="median")
+    with pytest.raises(ValueError, match="Target column 'nope' not found"):
+        calculate_domain_distances(ad, "dom_a", "nope")
+    with pytest.raises(ValueError, match="No valid source domains"):
+        calculate_domain_distances(ad, "dom_a", "dom_b", source_domain_subset=["zzz"])
+    with pytest.raises(KeyError):
+        get_distance_matrix(ad)

@@ -294,3 +294,25 @@ def test_profile_counts_golden(ctx):
     ctx.set_graph_csr(indptr, indices, np.ones(indices.size), coords.shape[0])
     cnt = ctx.profile_counts(code, len(cats))
     np.testing.assert_array_equal((cnt / cnt.sum(axis=1, keepdims=True)).astype(np.float32), g["radius_profile"])
+
+
+def test_nearest_and_pairwise_vs_scipy(ctx):
+    from scipy.spatial import cKDTree
+    from scipy.spatial.distance import cdist
+
+    rng = np.random.default_rng(12)
+    targets = rng.normal([300, 300], 40, (5000, 2))
+    queries = np.concatenate([rng.uniform(0, 1000, (3000, 2)),            # mostly far outside the target box
+                              rng.normal([300, 300], 40, (500, 2)),       # inside it
+                              [[-5e4, 7e4], [300.0, 300.0]]])
+    d, idx = ctx.nearest(targets, queries)
+    wd, wi = cKDTree(targets).query(queries, k=1)
+    np.testing.assert_array_equal(idx, wi)
+    np.testing.assert_array_equal(d, wd)
+    a, b = rng.uniform(0, 100, (1300, 2)), rng.uniform(50, 400, (2111, 2))
+    mean, mn = ctx.pairwise(a, b)
+    pw = cdist(a, b)
+    assert mn == pw.min()
+    assert mean == pytest.approx(pw.mean(), rel=1e-13)
+    one_mean, one_min = ctx.pairwise(a[:1], b[:1])
+    assert one_mean == one_min == pw[0, 0]
