@@ -358,7 +358,8 @@ __global__ __launch_bounds__(64) void k_apply_swaps(const int32_t *__restrict__ 
         const int64_t i = i_top - lane;
         const bool valid = i >= 1;
         // step index inside the permutation: s = n-1-i (lanes read consecutive entries)
-        const int32_t j = valid ? Jp[(int64_t)M - i] : -1;
+        int32_t j = valid ? Jp[(int64_t)M - i] : -1;
+        if (valid && (uint32_t)j > (uint32_t)i) j = (int32_t)i;  // never index outside [0, i], whatever J holds
         const int32_t ii = valid ? (int32_t)i : -2;
         // loads first (latency overlaps the conflict search); L1 is bypassed so that the values the
         // previous round stored (write-through to L2, completed by the vmcnt wait) are seen

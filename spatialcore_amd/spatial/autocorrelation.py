@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import pandas as pd
-from scipy import sparse, stats
+from scipy import stats
 from scipy.sparse import csr_matrix
 
 from spatialcore_amd import _lib
@@ -194,7 +194,7 @@ def _upload_existing_graph(ctx, g) -> None:
     g = csr_matrix(g, dtype=np.float64, copy=True)
     g.sum_duplicates()
     g.sort_indices()
-    rs = np.abs(g).sum(axis=1).A1 if hasattr(np.abs(g).sum(axis=1), "A1") else np.asarray(np.abs(g).sum(axis=1)).ravel()
+    rs = np.asarray(abs(g).sum(axis=1)).ravel()
     rs[rs == 0] = 1.0
     g.data = g.data / np.repeat(rs, np.diff(g.indptr))
     ctx.set_graph_csr(g.indptr, g.indices, g.data, g.shape[0])

@@ -1,0 +1,84 @@
+"""CPU property tests (hypothesis) of the host-side logic in spatialcore_amd."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from conftest import load_golden
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 60), st.integers(1, 400), st.integers(0, 2**32 - 1))
+def test_bh_from_counts_equals_reference_bh(n_perm, n_cells, seed):
+    """The O(P) count-level Benjamini-Hochberg used by local_morans_i gives, bit for bit, what the
+    reference's sort-based _fdr_correction_bh (AC:132-164) gives on p = float32((c + 1) / (P + 1)),
+    stored into a float32 column as the reference does (AC:912-914)."""
+    from spatialcore_amd.spatial.autocorrelation import _bh_from_counts, _fdr_correction_bh
+
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, n_perm + 1, n_cells).astype(np.int32)
+    if seed % 3 == 0:
+        counts[:] = rng.integers(0, n_perm + 1)          # all tied
+    p32 = ((counts + 1) / (n_perm + 1)).astype(np.float32)
+    want = np.ones(n_cells, dtype=np.float32)
+    want[:] = _fdr_correction_bh(p32)                   # float64 result assigned into a float32 column
+    got = _bh_from_counts(counts, n_perm)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, want)
+
+
+def test_bh_matches_reference_golden_values():
+    from spatialcore_amd.spatial.autocorrelation import _fdr_correction_bh
+
+    g = load_golden("ref_fdr_quadrants.npz")
+    np.testing.assert_array_equal(_fdr_correction_bh(g["p"]), g["bh"])
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(0, 5000), st.integers(1, 16))
+def test_shard_bounds_partition(n_items, world):
+    from spatialcore_amd.parallel import shard_bounds
+
+    cover = np.zeros(n_items, dtype=int)
+    for r in range(world):
+        a, b = shard_bounds(n_items, world, r)
+        assert 0 <= a <= b <= n_items
+        cover[a:b] += 1
+    assert (cover == 1).all()
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.lists(st.integers(0, 9), min_size=1, max_size=30))
+def test_unique_columns_roundtrip(picks):
+    from spatialcore_amd import SimpleAnnData
+    from spatialcore_amd.spatial.autocorrelation import _unique_columns
+
+    ad = SimpleAnnData(np.zeros((3, 10)), var_names=[f"g{i}" for i in range(10)])
+    names = [f"g{i}" for i in picks]
+    cols, where = _unique_columns(ad, names)
+    assert len(set(cols.tolist())) == len(cols)                     # distinct columns go to the device
+    assert [f"g{cols[w]}" for w in where] == names                   # every request maps back to its gene
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(0, 2**31 - 1), st.integers(1, 300), st.integers(1, 4))
+def test_host_generator_is_a_permutation_and_matches_numpy(seed, n, reps):
+    from spatialcore_amd import _lib
+
+    w = _lib.rng_state_words(np.random.default_rng(seed))
+    got = _lib.perm_numpy_host(w, n, reps)
+    rng = np.random.default_rng(seed)
+    for r in range(reps):
+        np.testing.assert_array_equal(got[r], rng.permutation(n))
+    np.testing.assert_array_equal(w, _lib.rng_state_words(rng))
+
+
+def test_quadrant_rules():
+    from spatialcore_amd.spatial.autocorrelation import QUADRANT_LABELS, _classify_quadrants
+
+    z = np.array([1.0, -1.0, 1.0, -1.0, 0.0, 2.0])
+    lag = np.array([1.0, -1.0, -1.0, 1.0, 3.0, 0.0])
+    q = _classify_quadrants(z, lag)
+    assert [QUADRANT_LABELS[v] for v in q] == ["HH", "LL", "HL", "LH", "NS", "NS"]
+    q = _classify_quadrants(z, lag, np.array([0.01, 0.05, 0.2, 0.049, 0.0, 0.0]), alpha=0.05)
+    assert [QUADRANT_LABELS[v] for v in q] == ["HH", "NS", "NS", "LH", "NS", "NS"]
+    assert q.dtype == np.int8
