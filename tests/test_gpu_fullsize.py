@@ -100,3 +100,90 @@ def test_moran_1m_invariants(big, oracle):
     vals = np.ascontiguousarray(X[:, :2].T, dtype=np.float64)
     np.testing.assert_allclose(got["I"][:2], oracle.morans_i_scores(g, vals), rtol=1e-9)
     np.testing.assert_allclose(got["sims"][0, :2], oracle.morans_i_sims_gather(g, vals, perm1)[0], rtol=1e-9)
+
+
+def test_config3_shape_radius_graph_and_lee_pairs(big, oracle):
+    """BASELINE configs[2] shape: 1M cells, radius graph r = 30 um, Lee's L for 100 x 100 gene pairs
+    (observed statistic; the reference has no radius option for Lee, so this is the kernel-level path)."""
+    from scipy.spatial import cKDTree
+    from scipy.sparse import csr_matrix
+
+    ctx, coords, _ = big
+    indptr, indices = ctx.radius_graph(coords, 30.0)
+    deg = np.diff(indptr)
+    assert indptr[0] == 0 and indptr[-1] == indices.size and 20 < deg.mean() < 36          # ~ pi * 30^2 / 100
+    rows = np.random.default_rng(1).choice(N, 2000, replace=False)
+    tree = cKDTree(coords)
+    for i in rows[:300]:
+        want = np.array(sorted(j for j in tree.query_ball_point(coords[i], 30.0) if j != i), dtype=np.int32)
+        np.testing.assert_array_equal(indices[indptr[i]:indptr[i + 1]], want)
+    assert (deg > 0).all()
+    w = 1.0 / np.repeat(deg, deg)
+    ctx.set_graph_csr(indptr, indices, w, N)
+    rng = np.random.default_rng(2)
+    G = 20                                                   # 10 x 10 distinct genes -> 100 ordered pairs
+    X = rng.poisson(rng.uniform(0.2, 3.0, G), (N, G)).astype(np.float32)
+    ctx.set_expression(X, np.arange(G))
+    px, py = np.meshgrid(np.arange(10), np.arange(10, 20), indexing="ij")
+    out = ctx.lee(px.ravel(), py.ravel(), None, 0)
+    L = out["L"].reshape(10, 10)
+    # definition on a sample of pairs: L = sum_i zx_i * (W zy)_i with population-std z-scores
+    W = csr_matrix((w, indices, indptr), shape=(N, N))
+    Z = (X.astype(np.float64) - X.mean(axis=0, dtype=np.float64)) / X.astype(np.float64).std(axis=0)
+    for a, b in [(0, 10), (3, 17), (9, 19), (5, 12)]:
+        want = float(Z[:, a] @ (W @ Z[:, b]))
+        assert L[a, b - 10] == pytest.approx(want, rel=1e-9, abs=1e-6)
+    # independent Poisson genes: L / N is a correlation-like quantity near 0
+    assert np.abs(L / N).max() < 0.01
+
+
+def test_config5_shape_k30_composition(big):
+    """BASELINE configs[4] shape: 1M cells, k = 30 neighbourhood composition (the reference's
+    compute_neighborhood_profile counting step; label-permutation enrichment is not in the reference)."""
+    from scipy.spatial import cKDTree
+
+    ctx, coords, _ = big
+    T = 20
+    labels = np.random.default_rng(3).choice(T, N, p=np.random.default_rng(4).dirichlet(np.ones(T))).astype(np.int32)
+    nbr = ctx.knn(coords, 30)
+    ctx.graph_from_knn(1.0)
+    cnt = ctx.profile_counts(labels, T)
+    assert cnt.dtype == np.float32 and (cnt.sum(axis=1) == 30).all()
+    rows = np.random.default_rng(5).choice(N, 2000, replace=False)
+    _, nb = cKDTree(coords).query(coords[rows], k=31)
+    np.testing.assert_array_equal(nbr[rows], nb[:, 1:])
+    want = np.stack([np.bincount(labels[nb[r, 1:]], minlength=T) for r in range(len(rows))]).astype(np.float32)
+    np.testing.assert_array_equal(cnt[rows], want)
+
+
+def test_config4_shape_5m_cells_indexing():
+    """BASELINE configs[3] per-GPU shape reduced in genes/permutations: 5M cells -- exercises 64-bit
+    offsets in tiles, permutation table, generator scratch and the pipelined scoring path."""
+    from scipy.spatial import cKDTree
+
+    from spatialcore_amd import _lib
+
+    n = 5_000_000
+    rng = np.random.default_rng(11)
+    coords = rng.uniform(0, np.sqrt(n) * 10.0, (n, 2))
+    G, P = 20, 12
+    X = rng.poisson(1.5, (n, G)).astype(np.float32)
+    with _lib.Context(0) as ctx:
+        idx = ctx.knn(coords, K)
+        rows = rng.choice(n, 1000, replace=False)
+        _, nb = cKDTree(coords).query(coords[rows], k=K + 1)
+        np.testing.assert_array_equal(idx[rows], nb[:, 1:])
+        ctx.graph_from_knn(1.0 / K)
+        ctx.set_expression(X, np.arange(G))
+        w = _lib.rng_state_words(np.random.default_rng(0))
+        out = ctx.moran_seeded(w, P)
+        wh = _lib.rng_state_words(np.random.default_rng(0))
+        host = _lib.perm_numpy_host(wh, n, P)                     # numpy-exact reference for the whole table
+        np.testing.assert_array_equal(w, wh)
+        np.testing.assert_array_equal(out["count_ge"], (out["sims"] >= out["I"]).sum(axis=0))
+        # the resident table equals the host table: score the host table explicitly and compare
+        ctx.set_permutations(host)
+        again = ctx.moran(P)
+        np.testing.assert_array_equal(again["sims"], out["sims"])
+        np.testing.assert_array_equal(again["I"], out["I"])
+        assert np.abs(out["I"]).max() < 0.01                      # i.i.d. genes
