@@ -184,6 +184,14 @@ int sc_pairwise_2d(sc_ctx *ctx, const double *xy_a, int64_t n_a, const double *x
 int sc_profile_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types,
                       float *counts_out, int64_t *n_empty_out);
 
+/* ---- N4 (extension; nothing in the reference computes this) -----------------------------------
+ * Cell-type pair counts over the active graph's edges for the observed labels and under label
+ * permutations labels[perm_p] (rows [perm_row0, perm_row0 + n_perm) of the active table):
+ * counts_out[(p * T + a) * T + b] = #{edges i -> j : type(i) = a, type(j) = b}; p = n_perm holds the
+ * observed counts.  Integer arithmetic, exact. */
+int sc_enrichment_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types, int64_t n_perm,
+                         int64_t perm_row0, int64_t *counts_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -550,3 +550,20 @@ def neighborhood_profile(coords, labels, method="knn", k=15, radius=None, normal
     if normalize:
         prof = prof / rs[:, None]
     return prof, cats
+
+
+# =============================================================================================
+# N4 -- label-permutation enrichment.  NOT in the reference: this restates the definition given
+# in spatialcore_amd.spatial.neighborhoods.neighborhood_enrichment ("parity unpinned" by nature).
+# =============================================================================================
+
+
+def enrichment_counts(indptr, indices, codes, n_types, perms):
+    """counts[p, a, b] over edges i -> j with labels codes[perm_p]; last slice = observed."""
+    codes = np.asarray(codes)
+    rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    out = np.zeros((len(perms) + 1, n_types, n_types), dtype=np.int64)
+    for p in range(len(perms) + 1):
+        lab = codes if p == len(perms) else codes[perms[p]]
+        np.add.at(out[p], (lab[rows], lab[indices]), 1)
+    return out

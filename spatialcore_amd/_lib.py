@@ -55,6 +55,7 @@ SYMBOLS = {
     "sc_nearest_2d": [_P, _P, c_int64, _P, c_int64, _P, _P],
     "sc_pairwise_2d": [_P, _P, c_int64, _P, c_int64, POINTER(c_double), POINTER(c_double)],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
+    "sc_enrichment_counts": [_P, _P, c_int64, c_int32, c_int64, c_int64, _P],
 }
 
 _lib = None
@@ -356,6 +357,15 @@ class Context:
         out = np.empty((lab.size, n_types), dtype=np.float32)
         empty = c_int64(0)
         _check(self._lib.sc_profile_counts(self._h, _ptr(lab), lab.size, int(n_types), _ptr(out), byref(empty)))
+        return out
+
+
+    # ---- N4 (extension) ---------------------------------------------------------------------
+    def enrichment_counts(self, labels, n_types: int, n_perm: int, perm_row0: int = 0) -> np.ndarray:
+        lab = _c(labels, np.int32)
+        out = np.empty((n_perm + 1, n_types, n_types), dtype=np.int64)
+        _check(self._lib.sc_enrichment_counts(self._h, _ptr(lab), lab.size, int(n_types), int(n_perm), int(perm_row0),
+                                              _ptr(out)))
         return out
 
 

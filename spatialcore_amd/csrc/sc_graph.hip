@@ -893,3 +893,75 @@ extern "C" int sc_pairwise_2d(sc_ctx *c, const double *xy_a, int64_t n_a, const 
     if (min_out) *min_out = m;
     return SC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// N4 (extension, no reference counterpart): cell-type pair counts over the graph's edges under label
+// permutations.  counts[p][a][b] = #{edges i -> j : lab[perm_p[i]] == a and lab[perm_p[j]] == b}
+// (p == n_perm: identity, i.e. the observed counts).  One workgroup = one permutation x one cell
+// range; the T x T histogram lives in LDS (integer atomics: deterministic), then is added to global.
+// ------------------------------------------------------------------------------------------------
+
+#define ENR_CELLS_PER_BLOCK 16384
+
+__global__ __launch_bounds__(256) void k_enrich(const long long *__restrict__ indptr,
+                                                const int32_t *__restrict__ indices,
+                                                const unsigned char *__restrict__ lab,
+                                                const int32_t *__restrict__ perm, int64_t pstride, int n_perm,
+                                                int64_t n, int n_types, unsigned long long *__restrict__ counts)
+{
+    extern __shared__ unsigned int hist[];
+    const int p = blockIdx.y;
+    const int tt = n_types * n_types;
+    for (int k = threadIdx.x; k < tt; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int32_t *prow = p < n_perm ? perm + (int64_t)p * pstride : nullptr;
+    const int64_t i0 = (int64_t)blockIdx.x * ENR_CELLS_PER_BLOCK;
+    const int64_t i1 = i0 + ENR_CELLS_PER_BLOCK < n ? i0 + ENR_CELLS_PER_BLOCK : n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int a = lab[prow ? prow[i] : (int32_t)i];
+        for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
+            const int32_t j = indices[e];
+            const int b = lab[prow ? prow[j] : j];
+            atomicAdd(&hist[a * n_types + b], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned long long *out = counts + (int64_t)p * tt;
+    for (int k = threadIdx.x; k < tt; k += 256)
+        if (hist[k]) atomicAdd(&out[k], (unsigned long long)hist[k]);
+}
+
+extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n, int32_t n_types, int64_t n_perm,
+                                    int64_t perm_row0, int64_t *counts_out)
+{
+    SC_REQUIRE(c && labels && counts_out, SC_ERR_INVALID, "sc_enrichment_counts: null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->g_n > 0 && n == c->g_n, SC_ERR_STATE, "sc_enrichment_counts: graph missing or size mismatch");
+    SC_REQUIRE(n_types >= 1 && n_types <= 96, SC_ERR_INVALID, "sc_enrichment_counts: n_types must be 1..96");
+    SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_enrichment_counts: negative size");
+    if (n_perm > 0)
+        SC_REQUIRE(c->p_n == n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
+                   "sc_enrichment_counts: needs permutation rows [%lld, %lld)", (long long)perm_row0,
+                   (long long)(perm_row0 + n_perm));
+    std::vector<unsigned char> lab8((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        SC_REQUIRE(labels[i] >= 0 && labels[i] < n_types, SC_ERR_INVALID, "label %d of cell %lld out of range",
+                   labels[i], (long long)i);
+        lab8[(size_t)i] = (unsigned char)labels[i];
+    }
+    const size_t tt = (size_t)n_types * n_types;
+    const size_t out_bytes = sizeof(unsigned long long) * tt * (size_t)(n_perm + 1);
+    SC_TRY(c->lee_pairs.ensure((size_t)n + 16, &c->mem));
+    SC_TRY(c->lee_b.ensure(out_bytes, &c->mem));
+    SC_HIP(hipMemcpyAsync(c->lee_pairs.p, lab8.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemsetAsync(c->lee_b.p, 0, out_bytes, c->stream));
+    dim3 grid((unsigned)ceil_div64(n, ENR_CELLS_PER_BLOCK), (unsigned)(n_perm + 1));
+    hipLaunchKernelGGL(k_enrich, grid, dim3(256), sizeof(unsigned int) * tt, c->stream, c->g_indptr.as<long long>(),
+                       c->g_indices.as<int32_t>(), c->lee_pairs.as<unsigned char>(),
+                       c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, n, (int)n_types,
+                       c->lee_b.as<unsigned long long>());
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(counts_out, c->lee_b.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}

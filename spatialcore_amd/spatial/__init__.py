@@ -9,7 +9,7 @@ from spatialcore_amd.spatial.autocorrelation import (
     morans_i,
 )
 from spatialcore_amd.spatial.distance import calculate_domain_distances, get_distance_matrix
-from spatialcore_amd.spatial.neighborhoods import compute_neighborhood_profile
+from spatialcore_amd.spatial.neighborhoods import compute_neighborhood_profile, neighborhood_enrichment
 
 __all__ = [
     "morans_i",
@@ -18,6 +18,7 @@ __all__ = [
     "lees_l_local",
     "build_spatial_weights",
     "compute_neighborhood_profile",
+    "neighborhood_enrichment",  # extension: not in the reference
     "calculate_domain_distances",
     "get_distance_matrix",
 ]

@@ -113,3 +113,104 @@ def compute_neighborhood_profile(
                  "n_celltypes": n_celltypes, "n_cells": n_cells},
     )
     return adata
+
+
+def neighborhood_enrichment(
+    adata,
+    celltype_column: str,
+    method: str = "knn",
+    k: int = 15,
+    radius: Optional[float] = None,
+    n_permutations: int = 1000,
+    seed: int = 0,
+    spatial_key: str = "spatial",
+    key_added: str = "neighborhood_enrichment",
+    copy: bool = False,
+    *,
+    device: int = 0,
+    perm_batch: int = 512,
+):
+    """Cell-type pair enrichment of the neighbourhood graph under label permutations.
+
+    EXTENSION -- the reference has no such function (its ``neighborhoods.py`` stops at
+    composition profiles and k-means niches); BASELINE.json's config 5 asks for it.  Semantics
+    defined here: on the same neighbour graph ``compute_neighborhood_profile`` uses,
+    ``count[a, b]`` = number of edges cell -> neighbour with types (a, b); the null is drawn by
+    permuting the label vector with the numpy-exact stream ``default_rng(seed).permutation(n_cells)``
+    (``labels[perm]``), ``n_permutations`` times.  Stored in ``adata.uns[key_added]``:
+    ``count``, ``mean``, ``std`` (population), ``zscore = (count - mean) / std``,
+    ``p_value = (#{perm count >= count} + 1) / (P + 1)`` as (T, T) arrays and ``celltypes``.
+    """
+    if spatial_key not in adata.obsm:
+        raise ValueError(f"adata.obsm['{spatial_key}'] not found. "
+                         "Spatial coordinates are required for neighborhood computation.")
+    if celltype_column not in adata.obs.columns:
+        raise ValueError(f"Column '{celltype_column}' not found in adata.obs. "
+                         f"Available columns: {list(adata.obs.columns)[:10]}...")
+    if method not in ["knn", "radius"]:
+        raise ValueError(f"Invalid method: '{method}'. Must be 'knn' or 'radius'.")
+    n_cells = adata.n_obs
+    if method == "knn" and not (1 <= k < n_cells):
+        raise ValueError(f"k must be >= 1 and < number of cells ({n_cells}), got {k}")
+    if method == "radius" and (radius is None or radius <= 0):
+        raise ValueError(f"radius must be > 0 when method='radius', got {radius}")
+    if n_permutations < 0:
+        raise ValueError(f"n_permutations must be >= 0, got {n_permutations}")
+    adata = adata.copy() if copy else adata
+    coords = np.ascontiguousarray(np.asarray(adata.obsm[spatial_key])[:, :2], dtype=np.float64)
+    series = adata.obs[celltype_column]
+    if series.isna().any():
+        raise ValueError(f"{int(series.isna().sum())} cells have missing labels in '{celltype_column}'. "
+                         "Fill or remove missing labels before computing neighborhoods.")
+    celltypes = sorted(series.unique())
+    code_of = {ct: i for i, ct in enumerate(celltypes)}
+    codes = np.fromiter((code_of[v] for v in series.values), dtype=np.int32, count=n_cells)
+    T = len(celltypes)
+    logger.info(f"Computing neighborhood enrichment: {n_cells:,} cells, {T} cell types, method={method}, "
+                f"permutations={n_permutations}")
+
+    ctx = _lib.default_context(device)
+    if method == "knn":
+        ctx.knn(coords, k, fetch=False)
+        ctx.graph_from_knn(1.0)
+    else:
+        indptr, indices = ctx.radius_graph(coords, float(radius))
+        ctx.set_graph_csr(indptr, indices, np.ones(indices.size), n_cells)
+
+    words = _lib.rng_state_words(np.random.default_rng(seed))
+    observed = None
+    s1 = np.zeros((T, T), dtype=np.float64)
+    s2 = np.zeros((T, T), dtype=np.float64)
+    ge = np.zeros((T, T), dtype=np.int64)
+    done = 0
+    while True:
+        batch = min(perm_batch, n_permutations - done)
+        if batch > 0:
+            ctx.generate_permutations(words, n_cells, batch)   # one stream, continued batch after batch
+        cnt = ctx.enrichment_counts(codes, T, batch)
+        observed = cnt[batch]
+        null = cnt[:batch].astype(np.float64)
+        s1 += null.sum(axis=0)
+        s2 += (null * null).sum(axis=0)
+        ge += (cnt[:batch] >= observed).sum(axis=0)
+        done += batch
+        if done >= n_permutations:
+            break
+    result = {"count": observed, "celltypes": list(celltypes), "n_permutations": n_permutations, "seed": seed}
+    if n_permutations > 0:
+        mean = s1 / n_permutations
+        var = np.maximum(s2 / n_permutations - mean * mean, 0.0)
+        std = np.sqrt(var)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = (observed - mean) / std
+        result.update({"mean": mean, "std": std, "zscore": z, "p_value": (ge + 1) / (n_permutations + 1)})
+    adata.uns[key_added] = result
+    update_metadata(
+        adata,
+        function_name="neighborhood_enrichment",
+        parameters={"celltype_column": celltype_column, "method": method, "k": k if method == "knn" else None,
+                    "radius": radius if method == "radius" else None, "n_permutations": n_permutations,
+                    "seed": seed, "spatial_key": spatial_key},
+        outputs={"uns": key_added, "n_celltypes": T, "n_cells": n_cells},
+    )
+    return adata

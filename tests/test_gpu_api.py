@@ -245,3 +245,41 @@ def test_calculate_domain_distances_golden():
         calculate_domain_distances(ad, "dom_a", "dom_b", source_domain_subset=["zzz"])
     with pytest.raises(KeyError):
         get_distance_matrix(ad)
+
+
+def test_neighborhood_enrichment_extension(oracle):
+    """N4 is an extension (nothing to match in the reference): checked against the oracle's restatement
+    of the definition, exact integer counts, numpy-exact label permutations continued across batches."""
+    from spatialcore_amd.spatial import neighborhood_enrichment
+
+    rng = np.random.default_rng(21)
+    n = 3000
+    coords = rng.uniform(0, 550, (n, 2))
+    # spatially structured labels: left half mostly A/B, right half mostly C/D
+    left = coords[:, 0] < 275
+    labels = np.where(left, rng.choice(["A", "B", "E"], n, p=[.5, .4, .1]), rng.choice(["C", "D", "E"], n, p=[.5, .4, .1]))
+    X = np.zeros((n, 1))
+    for kw in (dict(method="knn", k=8), dict(method="radius", radius=22.0)):
+        ad = make_adata(coords, X, labels=labels)
+        neighborhood_enrichment(ad, "cell_type", n_permutations=37, seed=5, perm_batch=16, **kw)
+        res = ad.uns["neighborhood_enrichment"]
+        cats = sorted(set(labels.tolist()))
+        assert res["celltypes"] == cats
+        codes = np.array([cats.index(v) for v in labels.tolist()])
+        if kw["method"] == "knn":
+            nbr = oracle.knn_bruteforce(coords, 8)
+            indptr, indices = np.arange(0, n * 8 + 1, 8), nbr.reshape(-1)
+        else:
+            indptr, indices = oracle.radius_neighbors(coords, 22.0)
+        perms, _ = oracle.perm_table(5, n, 37)
+        want = oracle.enrichment_counts(indptr, indices, codes, len(cats), perms)
+        np.testing.assert_array_equal(res["count"], want[-1])
+        null = want[:-1].astype(float)
+        np.testing.assert_allclose(res["mean"], null.mean(axis=0), rtol=1e-12)
+        np.testing.assert_allclose(res["std"], null.std(axis=0), rtol=1e-9, atol=1e-9)
+        np.testing.assert_array_equal(res["p_value"], ((want[:-1] >= want[-1]).sum(axis=0) + 1) / 38)
+        assert res["count"].sum() == indices.size
+        ia, ic = cats.index("A"), cats.index("C")
+        assert res["zscore"][ia, ia] > 3 and res["zscore"][ia, ic] < -3     # same-side types attract
+    with pytest.raises(ValueError, match="Invalid method"):
+        neighborhood_enrichment(ad, "cell_type", method="grid")
