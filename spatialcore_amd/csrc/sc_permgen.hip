@@ -71,17 +71,28 @@ __host__ __device__ static inline uint64_t xsl_rr(u128 s)
 // A0: the raw 32-bit stream, stored in the layout the scan reads.
 //
 // Stream draw r (r = 0: low half of 64-bit output 0, r = 1: its high half, ...) lives at
-//   phys(r) = (r & ~32767) + ((r >> 2) & 7) * 4096 + ((r >> 5) & 1023) * 4 + (r & 3)
-// i.e. inside every 32768-draw block, scan thread tau's draws [32 tau, 32 tau + 32) are stored as 8
-// groups of 4, group g at block + g*4096 + 4*tau: the scan's g-th 16-byte load is contiguous across
-// the 1024 threads.  One generator thread produces one such 16-byte group (2 consecutive 64-bit
+//   phys(r) = block(r) * SCAN_BLOCK + g * (4 * SCAN_THREADS) + tau * 4 + (r & 3),
+//   tau = (r % SCAN_BLOCK) / SCAN_D, g = ((r % SCAN_D) / 4)
+// i.e. inside every SCAN_BLOCK-draw block, scan thread tau's draws [D tau, D tau + D) are stored as D/4
+// groups of 4, group g at block + g*4*SCAN_THREADS + 4*tau: the scan's g-th 16-byte load is contiguous
+// across the workgroup's threads.  One generator thread produces one such 16-byte group (2 consecutive 64-bit
 // outputs) per block for RAW_BLOCKS consecutive blocks, stepping its LCG state by the constant
 // jump A^16384 between blocks.
 // ------------------------------------------------------------------------------------------------
 
+#ifndef SCAN_THREADS
 #define SCAN_THREADS 1024
+#endif
+#ifndef SCAN_D
 #define SCAN_D 32
+#endif
 #define SCAN_BLOCK (SCAN_THREADS * SCAN_D)
+#define SCAN_GROUPS (SCAN_D / 4)
+#if SCAN_D <= 32
+typedef uint32_t bits_t;
+#else
+typedef uint64_t bits_t;
+#endif
 #define RAW_BLOCKS 8
 
 __global__ __launch_bounds__(256) void k_raw_stream(uint64_t st_hi, uint64_t st_lo, uint64_t inc_hi,
@@ -94,11 +105,11 @@ __global__ __launch_bounds__(256) void k_raw_stream(uint64_t st_hi, uint64_t st_
     const u128 mult = pcg_mult();
     // thread = (block group, g, tau): consecutive threads write consecutive 16-byte groups
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tau = (uint32_t)(t & 1023), g = (uint32_t)((t >> 10) & 7);
-    uint64_t b = (t >> 13) * RAW_BLOCKS;
+    const uint32_t tau = (uint32_t)(t % SCAN_THREADS), g = (uint32_t)((t / SCAN_THREADS) % SCAN_GROUPS);
+    uint64_t b = (t / (SCAN_THREADS * SCAN_GROUPS)) * RAW_BLOCKS;
     if (b >= n_blocks) return;
     // first draw of the group: r = b*32768 + 32*tau + 4*g  ->  64-bit output m = r / 2
-    const uint64_t m = b * (SCAN_BLOCK / 2) + 16ull * tau + 2ull * g;
+    const uint64_t m = b * (SCAN_BLOCK / 2) + (uint64_t)(SCAN_D / 2) * tau + 2ull * g;
     const Affine j = lcg_pow(inc, m + 1);  // output m is made from the state after m + 1 steps
     u128 s = j.mult * state0 + j.plus;
     for (int k = 0; k < RAW_BLOCKS && b < n_blocks; ++k, ++b) {
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void k_raw_stream(uint64_t st_hi, uint64_t st_
         const uint64_t o1 = xsl_rr(s * mult + inc);
         uint4 v;
         v.x = (uint32_t)o0; v.y = (uint32_t)(o0 >> 32); v.z = (uint32_t)o1; v.w = (uint32_t)(o1 >> 32);
-        *reinterpret_cast<uint4 *>(raw + b * SCAN_BLOCK + (uint64_t)g * 4096 + 4ull * tau) = v;
+        *reinterpret_cast<uint4 *>(raw + b * SCAN_BLOCK + (uint64_t)g * (4 * SCAN_THREADS) + 4ull * tau) = v;
         s = jm * s + jp;
     }
 }
@@ -121,9 +132,9 @@ __device__ __forceinline__ uint32_t mask_of(uint32_t i) { return 0xffffffffu >> 
 struct ScanRes {
     uint32_t c_used;  // entering count (accepted steps of this block in front of the thread) it was computed for
     uint32_t cnt;     // accepted draws
-    uint32_t bits;    // accept mask, bit s = draw s accepted
-    uint32_t gacc;    // fast path: min over accepted draws of (threshold - value): they stay accepted while the
-    uint32_t grej;    //   entering count grows by <= gacc; grej: min over rejected of (value - threshold - 1)
+    bits_t bits;      // accept mask, bit s = draw s accepted
+    uint32_t gap;     // fast path: the entering count may move by up to +-gap without flipping any decision
+                      //   (min over draws of: threshold - value if accepted, value - threshold - 1 if rejected)
     uint32_t i0;      // threshold of the first draw
     uint32_t mask;    // fast path: the one mask used
     uint32_t fast;    // computed on the fast path
@@ -131,7 +142,7 @@ struct ScanRes {
 };
 
 // Sequential pass of one thread over its draws, entering with c accepted steps in front of it.
-__device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_t valid, uint32_t c_in,
+__device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_t c_in,
                                             uint32_t rem_block, uint32_t M, uint32_t top_mask, uint32_t limit,
                                             ScanRes &r)
 {
@@ -140,37 +151,38 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     const uint32_t i0 = rem - c;
     uint32_t mask = mask_of(i0);
     r.c_used = c_in; r.i0 = i0; r.mask = mask; r.end = 0;
-    // fast path: all 32 draws are stream draws and neither a mask change, nor the end of a
-    // permutation, nor the end of the job can happen within 32 accepts
-    if (valid == 0xffffffffu && i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit) {
-        uint32_t thr = i0, bits = 0, gacc = 0xffffffffu, grej = 0xffffffffu;
+    // fast path: neither a mask change, nor the end of a permutation, nor the end of the job can
+    // happen within SCAN_D accepts
+    if (i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit) {
+        uint32_t thr = i0, gap = 0xffffffffu;
+        bits_t bits = 0;
 #pragma unroll
         for (int s = 0; s < SCAN_D; ++s) {
             const uint32_t v = u[s] & mask;
-            const int32_t d = (int32_t)(thr - v);  // both < 2^31
-            const bool acc = d >= 0;
-            gacc = acc ? min(gacc, (uint32_t)d) : gacc;
-            grej = acc ? grej : min(grej, (uint32_t)(-d - 1));
-            bits |= (acc ? 1u : 0u) << s;
+            const int32_t d = (int32_t)(thr - v);        // both < 2^31; accepted iff d >= 0
+            const uint32_t acc = (uint32_t)(~d) >> 31;
+            gap = min(gap, (uint32_t)(d ^ (d >> 31)));   // d if accepted, -d - 1 if rejected
+            bits |= (bits_t)acc << s;
             thr -= acc;
         }
-        r.cnt = i0 - thr; r.bits = bits; r.gacc = gacc; r.grej = grej; r.fast = 1;
+        r.cnt = i0 - thr; r.bits = bits; r.gap = gap; r.fast = 1;
         return;
     }
-    uint32_t i = i0, off = c_in, cnt = 0, bits = 0;
+    uint32_t i = i0, off = c_in, cnt = 0;
+    bits_t bits = 0;
 #pragma unroll
     for (int s = 0; s < SCAN_D; ++s) {
         const uint32_t v = u[s] & mask;
-        const bool acc = ((valid >> s) & 1u) && off < limit && v <= i;
+        const bool acc = off < limit && v <= i;
         if (acc) {
-            bits |= 1u << s;
+            bits |= (bits_t)1 << s;
             ++off; ++cnt; --i;
             if (off == limit) r.end = (uint32_t)s + 1;
             if (i == 0) { i = M; mask = top_mask; }
             else if (i <= (mask >> 1)) mask >>= 1;
         }
     }
-    r.cnt = cnt; r.bits = bits; r.gacc = 0; r.grej = 0; r.fast = 0;
+    r.cnt = cnt; r.bits = bits; r.gap = 0; r.fast = 0;
 }
 
 // Is the cached result still the exact result for entering count c_new?  On the fast path every
@@ -183,7 +195,7 @@ __device__ __forceinline__ bool scan_still_valid(const ScanRes &r, uint32_t c_ne
     const int64_t i0n = (int64_t)r.i0 - delta;  // new first threshold (same permutation, same band required)
     if (i0n > (int64_t)M || i0n > (int64_t)r.mask || i0n <= (int64_t)(r.mask >> 1) + SCAN_D) return false;
     if ((uint64_t)c_new + SCAN_D >= limit) return false;
-    return delta > 0 ? (uint64_t)delta <= r.gacc : (uint64_t)(-delta) <= r.grej;
+    return (uint64_t)(delta > 0 ? delta : -delta) <= r.gap;
 }
 
 // thread tau's 32 draws of the block at `base` (tiled layout, see k_raw_stream): 8 coalesced loads
@@ -193,7 +205,7 @@ __device__ __forceinline__ void scan_load(const uint32_t *__restrict__ raw, uint
     const uint4 *src = reinterpret_cast<const uint4 *>(raw + base) + tau;
 #pragma unroll
     for (int q = 0; q < SCAN_D / 4; ++q) {
-        const uint4 v = src[q * 1024];
+        const uint4 v = src[q * SCAN_THREADS];
         u[4 * q] = v.x; u[4 * q + 1] = v.y; u[4 * q + 2] = v.z; u[4 * q + 3] = v.w;
     }
 }
@@ -211,7 +223,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 }
 
 // Per processed block the scan leaves: sblk[b] = steps completed before the block, and per thread
-// acc_bits[b*1024 + tau], enter[b*1024 + tau] (accepted steps of the block in front of the thread).
+// acc_bits[b*SCAN_THREADS + tau], enter[b*SCAN_THREADS + tau] (accepted steps of the block in front of the thread).
 // k_expand turns these into J with the whole chip; one CU cannot store 4 bytes per step fast enough.
 //
 // st[0] = steps completed so far, st[1] = next block to process, st[2] = sticky failure flag,
@@ -220,13 +232,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 // run past the target; only the end of the job, total_steps, stops mid-block).
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restrict__ raw, uint64_t n_blocks,
                                                        uint32_t n, uint64_t S_target, uint64_t total_steps,
-                                                       uint32_t *__restrict__ acc_bits,
+                                                       bits_t *__restrict__ acc_bits,
                                                        uint32_t *__restrict__ enter,
                                                        unsigned long long *__restrict__ sblk,
                                                        unsigned long long *__restrict__ st)
 {
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
     __shared__ uint32_t wchg[2][SCAN_THREADS / 64];
+    static_assert(SCAN_THREADS % 64 == 0 && SCAN_D % 4 == 0 && SCAN_D <= 64, "scan geometry");
     const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
     const uint32_t M = n - 1;
     const uint32_t top_mask = mask_of(M);
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restric
         const uint32_t limit = left > 0xffffffffULL ? 0xffffffffu : (uint32_t)left;
         const float p_acc = (float)(rem_block + 1.0) / (float)((double)mask_of(rem_block) + 1.0);
         ScanRes r;
-        scan_thread(u, 0xffffffffu, (uint32_t)((float)(tau * SCAN_D) * p_acc), rem_block, M, top_mask, limit, r);
+        scan_thread(u, (uint32_t)((float)(tau * SCAN_D) * p_acc), rem_block, M, top_mask, limit, r);
         uint32_t excl = 0, total_cnt = 0;
         // fixed point on the entering counts: a thread recomputes only when its cached result is
         // not provably the result for its new entering count
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restric
             parity ^= 1u;
             if (!changed) break;
             if (wave_stale) {
-                if (stale) scan_thread(u, 0xffffffffu, excl, rem_block, M, top_mask, limit, r);
+                if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
             }
             if (iter > SCAN_THREADS + 8) { failed = 1; break; }
         }
@@ -301,19 +314,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restric
 // J[step] for every accepted draw of blocks [st_prev_block, st[1]) -- the whole chip, one thread per
 // scan thread.  blk0 = first block of this range (read from st_range[0]), end = st_range[1].
 __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw,
-                                                const uint32_t *__restrict__ acc_bits,
+                                                const bits_t *__restrict__ acc_bits,
                                                 const uint32_t *__restrict__ enter,
                                                 const unsigned long long *__restrict__ sblk,
                                                 const unsigned long long *__restrict__ range, uint32_t n,
                                                 uint64_t total_steps, int32_t *__restrict__ J)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tau = (uint32_t)(t & 1023);
+    const uint32_t tau = (uint32_t)(t % SCAN_THREADS);
     const uint32_t M = n - 1;
     const uint32_t top_mask = mask_of(M);
-    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 10;
-    for (uint64_t b = range[0] + (t >> 10); b < range[1]; b += stride) {
-        const uint32_t bits = acc_bits[b * SCAN_THREADS + tau];
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) / SCAN_THREADS;
+    for (uint64_t b = range[0] + t / SCAN_THREADS; b < range[1]; b += stride) {
+        const bits_t bits = acc_bits[b * SCAN_THREADS + tau];
         if (!bits) continue;
         uint64_t S = sblk[b] + enter[b * SCAN_THREADS + tau];
         uint32_t i = M - (uint32_t)(S % M);
@@ -321,12 +334,12 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
         const uint4 *src = reinterpret_cast<const uint4 *>(raw + b * SCAN_BLOCK) + tau;
 #pragma unroll
         for (int q = 0; q < SCAN_D / 4; ++q) {
-            if (!((bits >> (4 * q)) & 0xfu)) continue;
-            const uint4 v4 = src[q * 1024];
+            if (!((uint32_t)(bits >> (4 * q)) & 0xfu)) continue;
+            const uint4 v4 = src[q * SCAN_THREADS];
             const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if ((bits >> (4 * q + e)) & 1u) {
+                if ((uint32_t)(bits >> (4 * q + e)) & 1u) {
                     if (S < total_steps) J[S] = (int32_t)(vv[e] & mask);
                     ++S; --i;
                     if (i == 0) { i = M; mask = top_mask; }
@@ -426,7 +439,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     job->hi = n_blocks * SCAN_BLOCK;  // raw draw r = half (r & 1) of 64-bit output r / 2
     SC_TRY(c->pg_raw.ensure(sizeof(uint32_t) * (size_t)job->hi, &c->mem));
     SC_TRY(c->pg_J.ensure(sizeof(int32_t) * (size_t)job->total_steps, &c->mem));
-    SC_TRY(c->pg_bits.ensure(sizeof(uint32_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
+    SC_TRY(c->pg_bits.ensure(sizeof(bits_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
     SC_TRY(c->pg_enter.ensure(sizeof(uint32_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
     SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)n_blocks, &c->mem));
     // pg_out: [0..3] scan state, then one {first block, end block} pair per chunk for k_expand
@@ -449,7 +462,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     SC_HIP(hipMemcpyAsync(c->pg_out.p, st0, sizeof(st0), hipMemcpyHostToDevice, s));
     SC_HIP(hipStreamSynchronize(s));  // st0 / j0 are stack variables
     const Affine jb = lcg_pow(inc, SCAN_BLOCK / 2);
-    const uint64_t threads = ((n_blocks + RAW_BLOCKS - 1) / RAW_BLOCKS) * 8192;
+    const uint64_t threads = ((n_blocks + RAW_BLOCKS - 1) / RAW_BLOCKS) * (uint64_t)(SCAN_THREADS * SCAN_GROUPS);
     hipLaunchKernelGGL(k_raw_stream, dim3((unsigned)(threads / 256)), dim3(256), 0, s, job->st_hi, job->st_lo,
                        job->inc_hi, job->inc_lo, n_blocks, (uint64_t)(jb.mult >> 64), (uint64_t)jb.mult,
                        (uint64_t)(jb.plus >> 64), (uint64_t)jb.plus, c->pg_raw.as<uint32_t>());
@@ -471,7 +484,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
     {
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
-                           (uint32_t)job->n, target, job->total_steps, c->pg_bits.as<uint32_t>(),
+                           (uint32_t)job->n, target, job->total_steps, c->pg_bits.as<bits_t>(),
                            c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
     }
     SC_HIP(hipMemcpyAsync(range + 1, st + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
@@ -479,7 +492,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
     const double chunk_perms = (double)(p1 - job->p_done);
     const uint64_t max_blocks = (uint64_t)(chunk_perms * job->draws_per_perm * 1.01 / SCAN_BLOCK) + 3;
     hipLaunchKernelGGL(k_expand, dim3((unsigned)(max_blocks * SCAN_THREADS / 256)), dim3(256), 0, s,
-                       c->pg_raw.as<uint32_t>(), c->pg_bits.as<uint32_t>(), c->pg_enter.as<uint32_t>(),
+                       c->pg_raw.as<uint32_t>(), c->pg_bits.as<bits_t>(), c->pg_enter.as<uint32_t>(),
                        c->pg_sblk.as<unsigned long long>(), range, (uint32_t)job->n, job->total_steps,
                        c->pg_J.as<int32_t>());
     SC_HIP(hipGetLastError());
