@@ -25,6 +25,7 @@ class SimpleAnnData:
         X,
         obs: Optional[pd.DataFrame] = None,
         var_names: Optional[Sequence[str]] = None,
+        var: Optional[pd.DataFrame] = None,
         obsm: Optional[Dict[str, Any]] = None,
         obsp: Optional[Dict[str, Any]] = None,
         layers: Optional[Dict[str, Any]] = None,
@@ -41,6 +42,9 @@ class SimpleAnnData:
         self.var_names = pd.Index([str(v) for v in var_names])
         if len(self.var_names) != n_vars:
             raise ValueError("len(var_names) must equal X.shape[1]")
+        self.var = pd.DataFrame(index=self.var_names) if var is None else var
+        if len(self.var) != n_vars:
+            raise ValueError("len(var) must equal X.shape[1]")
         if obs is None:
             obs = pd.DataFrame(index=pd.RangeIndex(n_obs).astype(str))
         if len(obs) != n_obs:
@@ -74,6 +78,7 @@ class SimpleAnnData:
             self.X.copy(),
             obs=self.obs.copy(),
             var_names=list(self.var_names),
+            var=self.var.copy(),
             obsm={k: _copy.deepcopy(v) for k, v in self.obsm.items()},
             obsp={k: v.copy() for k, v in self.obsp.items()},
             layers={k: v.copy() for k, v in self.layers.items()},
@@ -96,6 +101,7 @@ class SimpleAnnData:
             X,
             obs=self.obs,
             var_names=[self.var_names[c] for c in cols],
+            var=self.var.iloc[cols],
             obsm=self.obsm,
             obsp=self.obsp,
             layers=layers,

@@ -274,6 +274,16 @@ def morans_i(
     n_cells, n_genes = adata.n_obs, len(gene_names)
     logger.info(f"Computing Global Moran's I: {n_cells:,} cells, {n_genes} genes, "
                 f"k={n_neighbors}, permutations={n_permutations}")
+    # The reference calls sq.gr.spatial_autocorr without `genes=` (AC:576-583); squidpy then keeps only
+    # adata.var['highly_variable'] genes when that column exists [upstream], and the reference's result
+    # loop fails for every other requested gene (AC:617-621).  Same inputs, same failure.
+    var = getattr(adata, "var", None)
+    if var is not None and "highly_variable" in getattr(var, "columns", []):
+        hv = np.asarray(var["highly_variable"].loc[gene_names].values, dtype=bool)
+        if not hv.all():
+            gene_name = gene_names[int(np.flatnonzero(~hv)[0])]
+            raise RuntimeError(f"Gene '{gene_name}' was passed to squidpy but not found in results. "
+                               "This indicates an internal error in squidpy or data corruption.")
 
     ctx = _lib.default_context(device)
     if use_existing_graph and "spatial_connectivities" in adata.obsp:

@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build libspatialcore_hip.so (hipcc cross-compiles without a GPU) and liboracle.so if they are
+    missing or stale, so that the suite does not depend on a prior manual build."""
+    import subprocess
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "spatialcore_amd", "csrc"), "-j4"],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -147,6 +147,21 @@ def test_argument_validation_happens_before_the_gpu_is_touched():
         compute_neighborhood_profile(ad, "cell_type")
 
 
+def test_morans_i_highly_variable_quirk_is_mirrored():
+    """AC:576-583 + AC:617-621: with a var['highly_variable'] column the reference fails for non-HVG genes."""
+    import pandas as pd
+
+    from spatialcore_amd import SimpleAnnData
+    from spatialcore_amd.spatial import morans_i
+
+    coords, X = synth(60, 3, 1)
+    var = pd.DataFrame({"highly_variable": [True, False, True]}, index=["g0", "g1", "g2"])
+    ad = SimpleAnnData(X, var_names=["g0", "g1", "g2"], var=var, obsm={"spatial": coords})
+    with pytest.raises(RuntimeError, match="Gene 'g1' was passed to squidpy but not found in results"):
+        morans_i(ad, genes=["g0", "g1"], n_permutations=2)
+    assert list(ad[:, ["g2", "g0"]].var["highly_variable"]) == [True, True]
+
+
 def test_shard_bounds_cover_everything_once():
     from spatialcore_amd.parallel import shard_bounds
 
