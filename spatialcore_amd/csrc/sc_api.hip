@@ -145,7 +145,7 @@ int sc_ctx_destroy(sc_ctx *c)
     DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,
                     &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->rad_indptr,
                     &c->g_indptr, &c->g_indices, &c->g_data, &c->gt_indptr, &c->gt_indices,
-                    &c->gt_data, &c->gt_cursor, &c->X, &c->Z, &c->Lag, &c->e_tmp_indptr,
+                    &c->gt_data, &c->gt_cursor, &c->X, &c->Z, &c->Lag, &c->X32, &c->inv, &c->e_tmp_indptr,
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,

@@ -90,6 +90,8 @@ struct sc_ctx {
     int64_t e_n = 0, e_genes = 0, e_tiles = 0;
     int e_dtype = SC_F64;  // dtype of the matrix the tiles were loaded from (the reference's float32 paths depend on it)
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
+    DBuf X32;            // [tile32][cell][32] float: the raw values again, when they are float32-exact
+    bool x32_valid = false, x32_exact = false;
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene
 
@@ -97,6 +99,9 @@ struct sc_ctx {
     int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)
     DBuf perm;
     DBuf perm_flag;
+    DBuf inv;                      // inverse permutations, same layout as perm (rows valid on demand)
+    bool perm_bijective = false;   // the active table is known to hold true permutations
+    bool perm_checked = false;     // ... or was checked and is not
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
 
     // ---- Moran / Lee work buffers ----

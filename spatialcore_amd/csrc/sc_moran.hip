@@ -72,6 +72,8 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     c->e_n = n;
     c->e_genes = n_genes;
     c->e_tiles = tiles;
+    c->x32_valid = false;
+    c->x32_exact = false;
     return SC_OK;
 }
 
@@ -480,6 +482,139 @@ __global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// A5, half the gathered bytes: the same statistic summed over the TARGET cell,
+//
+//   sims[p][g] = scale_g * sum_j lag_g[j] * z_g[inv_p[j]],   inv_p = perm_p^-1,   z = (double)x - mean
+//
+// z is rebuilt in registers from the raw value x, which is exact whenever x is a float32 (AnnData's
+// usual dtype; checked on the device): (double)x - mean is the very subtraction k_center performs, so
+// every product is bit-identical to the fp64-tile kernel's.  The gathered operand is then a 128-byte
+// row of 32 float32 genes instead of a 128-byte row of 16 fp64 genes; the fp64 lag is the streamed,
+// coalesced operand (two 16-gene tiles side by side).  Lane = (permutation r, 4 genes q).
+// ------------------------------------------------------------------------------------------------
+
+// X32[t32][cell][32] = (float)X[2*t32 + (slot >> 4)][cell][slot & 15]; *inexact |= (double)(float)x != x
+__global__ __launch_bounds__(256) void k_pack_x32(const double *__restrict__ X, float *__restrict__ X32, int64_t n,
+                                                  int64_t tiles16, int *__restrict__ inexact)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (cell, q)
+    if (t >= n * 8) return;
+    const int64_t cell = t >> 3;
+    const int q = (int)(t & 7);
+    const int64_t t16 = 2 * (int64_t)blockIdx.y + (q >> 2);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t16 < tiles16) {
+        const double *src = X + t16 * n * SC_TILE + cell * SC_TILE + (q & 3) * 4;
+        const double2 a = reinterpret_cast<const double2 *>(src)[0], b = reinterpret_cast<const double2 *>(src)[1];
+        o = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+        if ((double)o.x != a.x || (double)o.y != a.y || (double)o.z != b.x || (double)o.w != b.y) atomicOr(inexact, 1);
+    }
+    reinterpret_cast<float4 *>(X32)[((int64_t)blockIdx.y * n + cell) * 8 + q] = o;
+}
+
+#define INV_BLOCKS_PER_ROW 64
+
+// inv[row][perm[row][i]] = i.  Blocks of one row share blockIdx % 8 (one XCD under round-robin placement,
+// speed only) so that the 4n-byte inverse row is assembled in one L2.
+__global__ __launch_bounds__(256) void k_invert_perm(const int32_t *__restrict__ perm, int32_t *__restrict__ inv,
+                                                     int64_t n, int64_t stride, int rows)
+{
+    const int id = blockIdx.x;
+    const int rest = id >> 3;
+    const int row = (rest / INV_BLOCKS_PER_ROW) * 8 + (id & 7);
+    const int part = rest % INV_BLOCKS_PER_ROW;
+    if (row >= rows) return;
+    const int64_t per = (n + INV_BLOCKS_PER_ROW - 1) / INV_BLOCKS_PER_ROW;
+    const int64_t i0 = (int64_t)part * per, i1 = i0 + per < n ? i0 + per : n;
+    const int32_t *src = perm + (int64_t)row * stride;
+    int32_t *dst = inv + (int64_t)row * stride;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) dst[src[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ inv, int64_t n, int64_t stride,
+                                                       int64_t rows, int *__restrict__ flag)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = rows * n;
+    int bad = 0;
+    for (; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n, i = t - r * n;
+        if (inv[r * stride + perm[r * stride + i]] != (int32_t)i) bad = 1;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_moran_perm32(const float *__restrict__ X32t, const double *__restrict__ LagA,
+                                                      const double *__restrict__ LagB,
+                                                      const double *__restrict__ meanA,
+                                                      const double *__restrict__ meanB,
+                                                      const int32_t *__restrict__ inv, double *__restrict__ partial,
+                                                      int64_t n, int64_t pstride, int n_perm, int64_t cells_per_split)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane >> 3, q = lane & 7;
+    const int pbase = blockIdx.y * MP_PERMS_PER_BLOCK + wave * 8;
+    if (pbase >= n_perm) return;  // whole wavefront idle (no barriers in this kernel)
+    const int p = pbase + r;
+    const int pc = p < n_perm ? p : n_perm - 1;
+    const int64_t c0 = (int64_t)blockIdx.x * cells_per_split;
+    int64_t c1 = c0 + cells_per_split;
+    if (c1 > n) c1 = n;
+    const int32_t *irow = inv + (int64_t)pc * pstride;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X32t) + q;                 // row j: X4[j * 8]
+    const double2 *L2 = reinterpret_cast<const double2 *>((q < 4 ? LagA : LagB)) + (q & 3) * 2;  // row j: L2[j * 8], +1
+    const double *mp = (q < 4 ? meanA : meanB) + (q & 3) * 4;
+    const double m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t j = c0;  // multiple of 8
+    for (; j + 4 <= c1; j += 4) {
+        const int4 id = *reinterpret_cast<const int4 *>(irow + j);
+        const float4 x0 = X4[(int64_t)id.x * 8];
+        const float4 x1 = X4[(int64_t)id.y * 8];
+        const float4 x2 = X4[(int64_t)id.z * 8];
+        const float4 x3 = X4[(int64_t)id.w * 8];
+        const double2 l0a = L2[(j + 0) * 8], l0b = L2[(j + 0) * 8 + 1];
+        const double2 l1a = L2[(j + 1) * 8], l1b = L2[(j + 1) * 8 + 1];
+        const double2 l2a = L2[(j + 2) * 8], l2b = L2[(j + 2) * 8 + 1];
+        const double2 l3a = L2[(j + 3) * 8], l3b = L2[(j + 3) * 8 + 1];
+        a0 = fma(l0a.x, (double)x0.x - m0, a0); a1 = fma(l0a.y, (double)x0.y - m1, a1);
+        a2 = fma(l0b.x, (double)x0.z - m2, a2); a3 = fma(l0b.y, (double)x0.w - m3, a3);
+        a0 = fma(l1a.x, (double)x1.x - m0, a0); a1 = fma(l1a.y, (double)x1.y - m1, a1);
+        a2 = fma(l1b.x, (double)x1.z - m2, a2); a3 = fma(l1b.y, (double)x1.w - m3, a3);
+        a0 = fma(l2a.x, (double)x2.x - m0, a0); a1 = fma(l2a.y, (double)x2.y - m1, a1);
+        a2 = fma(l2b.x, (double)x2.z - m2, a2); a3 = fma(l2b.y, (double)x2.w - m3, a3);
+        a0 = fma(l3a.x, (double)x3.x - m0, a0); a1 = fma(l3a.y, (double)x3.y - m1, a1);
+        a2 = fma(l3b.x, (double)x3.z - m2, a2); a3 = fma(l3b.y, (double)x3.w - m3, a3);
+    }
+    for (; j < c1; ++j) {
+        const float4 x = X4[(int64_t)irow[j] * 8];
+        const double2 la = L2[j * 8], lb = L2[j * 8 + 1];
+        a0 = fma(la.x, (double)x.x - m0, a0); a1 = fma(la.y, (double)x.y - m1, a1);
+        a2 = fma(lb.x, (double)x.z - m2, a2); a3 = fma(lb.y, (double)x.w - m3, a3);
+    }
+    if (p < n_perm) {
+        double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)blockIdx.x * n_perm + p) * 32 + 4 * q) / 2;
+        out[0] = make_double2(a0, a1);
+        out[1] = make_double2(a2, a3);
+    }
+}
+
+// sims[p0 + p][g0 + slot] = scale[g0 + slot] * sum_s partial[s][p][slot], slot < 32   (ascending s)
+__global__ __launch_bounds__(256) void k_moran_finalize32(const double *__restrict__ partial,
+                                                          const double *__restrict__ scale,
+                                                          double *__restrict__ sims, int n_perm, int splits,
+                                                          int64_t n_genes, int64_t g0, int64_t g_end, int64_t p0)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = t >> 5, slot = t & 31;
+    if (p >= n_perm || g0 + slot >= g_end) return;
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += partial[((int64_t)k * n_perm + p) * 32 + slot];
+    sims[(p0 + p) * n_genes + g0 + slot] = scale[g0 + slot] * s;
+}
+
 static int pick_splits(int64_t n, int n_perm_tiles, int64_t *cells_per_split)
 {
     // aim for >= 2048 workgroups per launch (256 CUs x 8 resident), splits <= 256,
@@ -525,13 +660,63 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm)
         // partial sums for one chunk of permutations (<= PERM_CHUNK, or all of them in the unfused call)
         int64_t cps = 0;
         int splits = pick_splits(n, 1, &cps);  // upper bound on the split count
-        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * SC_TILE, &c->mem));
+        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * 32, &c->mem));
+        if (!c->x32_valid) {  // float32 copy of the raw values for the half-traffic kernel, if that is exact
+            const int64_t T32 = (T + 1) / 2;
+            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));
+            SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
+            SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_pack_x32, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)T32), dim3(256), 0, c->stream,
+                               c->X.as<double>(), c->X32.as<float>(), n, T, c->perm_flag.as<int>());
+            int inexact = 0;
+            SC_HIP(hipMemcpyAsync(&inexact, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            SC_HIP(hipStreamSynchronize(c->stream));
+            c->x32_exact = (inexact == 0);
+            c->x32_valid = true;
+        }
     }
     return SC_OK;
 }
 
-// score permutations [p0, p1) of the active table for every gene tile (on the context stream)
-static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1)
+// inverse rows [p0, p1) of the active table on stream s
+static int invert_rows(sc_ctx *c, int64_t p0, int64_t p1, hipStream_t s)
+{
+    const int rows = (int)(p1 - p0);
+    if (rows <= 0) return SC_OK;
+    const int groups = (rows + 7) / 8;
+    hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(groups * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0, s,
+                       c->perm.as<int32_t>() + p0 * c->p_stride, c->inv.as<int32_t>() + p0 * c->p_stride, c->e_n,
+                       c->p_stride, rows);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+// Decide whether the half-traffic kernel may be used for the active table; a table uploaded by the
+// caller is only trusted after checking that every row is a bijection (inverse of the inverse).
+static int moran_choose_path(sc_ctx *c, int64_t n_perm, bool *use32)
+{
+    *use32 = false;
+    if (n_perm <= 0 || !c->x32_exact) return SC_OK;
+    SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
+    if (!c->perm_bijective && !c->perm_checked) {
+        SC_TRY(invert_rows(c, 0, n_perm, c->stream));
+        SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
+        SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_check_inverse, dim3(2048), dim3(256), 0, c->stream, c->perm.as<int32_t>(),
+                           c->inv.as<int32_t>(), c->e_n, c->p_stride, n_perm, c->perm_flag.as<int>());
+        int bad = 0;
+        SC_HIP(hipMemcpyAsync(&bad, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipStreamSynchronize(c->stream));
+        c->perm_checked = true;
+        c->perm_bijective = (bad == 0);
+    }
+    *use32 = c->perm_bijective;
+    return SC_OK;
+}
+
+// score permutations [p0, p1) of the active table for every gene tile (on the context stream).
+// use32: half-traffic kernel (needs inverse rows [p0, p1); invert_here launches that inversion first).
+static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, bool use32, bool invert_here)
 {
     const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
     const size_t tile_elems = (size_t)n * SC_TILE;
@@ -540,6 +725,27 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1)
     const int ptiles = (int)ceil_div64(cnt, MP_PERMS_PER_BLOCK);
     int64_t cps = 0;
     const int splits = pick_splits(n, ptiles, &cps);
+    if (use32) {
+        if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
+        const int64_t T32 = (T + 1) / 2;
+        for (int64_t t = 0; t < T32; ++t) {
+            const int64_t ta = 2 * t, tb = 2 * t + 1 < T ? 2 * t + 1 : 2 * t;  // odd tile count: B mirrors A, unused
+            {
+                KernelTimerScope ts(c, SC_K_MORAN_PERM);
+                hipLaunchKernelGGL(k_moran_perm32, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
+                                   c->X32.as<float>() + (size_t)t * n * 32, c->Lag.as<double>() + ta * tile_elems,
+                                   c->Lag.as<double>() + tb * tile_elems, c->g_mean.as<double>() + ta * SC_TILE,
+                                   c->g_mean.as<double>() + tb * SC_TILE, c->inv.as<int32_t>() + p0 * c->p_stride,
+                                   c->partial.as<double>(), n, c->p_stride, cnt, cps);
+            }
+            const int64_t g_hi = (2 * t + 2) * SC_TILE < G ? (2 * t + 2) * SC_TILE : G;  // genes of the tile pair
+            hipLaunchKernelGGL(k_moran_finalize32, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256)), dim3(256), 0,
+                               c->stream, c->partial.as<double>(), c->g_scale.as<double>(), c->sims.as<double>(), cnt,
+                               splits, G, ta * SC_TILE, g_hi, p0);
+        }
+        SC_HIP(hipGetLastError());
+        return SC_OK;
+    }
     for (int64_t t = 0; t < T; ++t) {
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
@@ -599,8 +805,10 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1),
                           &c->mem));
+    bool use32 = false;
+    SC_TRY(moran_choose_path(c, n_perm, &use32));
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK)
-        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm));
+        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm, use32, true));
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
@@ -616,6 +824,7 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     // allocations first (hipMalloc synchronises the device), then the two streams run freely
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
+    SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
     // chunk schedule: a short first chunk so that scoring starts early, then PERM_CHUNK each
     std::vector<int64_t> bounds;
     bounds.push_back(0);
@@ -645,6 +854,8 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
             rc = SC_ERR_HIP;
         }
         if (rc == SC_OK) rc = permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], c->stream3);
+        // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
+        if (rc == SC_OK) rc = invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], c->stream3);
         if (rc == SC_OK && hipEventRecord(swapped, c->stream3) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
@@ -652,12 +863,14 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     }
     // observed statistic, lag, graph moments (host-blocking in places) overlap the first scan chunk
     if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
+    c->perm_bijective = true;  // device-generated rows are permutations by construction
+    const bool use32 = c->x32_exact;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
         if (hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1]);
+        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1], use32, false);
     }
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);

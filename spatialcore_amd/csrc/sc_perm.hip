@@ -130,6 +130,8 @@ int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
     c->p_n = n;
     c->p_count = 0;
     c->p_stride = stride;
+    c->perm_bijective = false;
+    c->perm_checked = false;
     return SC_OK;
 }
 
@@ -164,6 +166,7 @@ extern "C" int sc_perm_generate(sc_ctx *c, uint64_t *state6, int64_t n, int64_t 
         SC_TRY(sc_perm_generate_device(c, state6, n, n_perm));
     }
     c->p_count = n_perm;
+    c->perm_bijective = true;  // generated rows are permutations by construction
     if (perm_out) {
         SC_HIP(hipMemcpy2DAsync(perm_out, sizeof(int32_t) * (size_t)n, c->perm.p, sizeof(int32_t) * (size_t)c->p_stride,
                                 sizeof(int32_t) * (size_t)n, (size_t)n_perm, hipMemcpyDeviceToHost, c->stream));
