@@ -61,6 +61,16 @@ int sc_ctx_reset_timers(sc_ctx *ctx);
 /* Enable/disable per-launch HIP-event timing (default on; events are recorded on the ctx stream). */
 int sc_ctx_set_timing(sc_ctx *ctx, int enabled);
 int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
+/* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream
+ * (results are identical in every mode): 0 = automatic (block-parallel scan for n >= 131072, verified on the
+ * device, sequential scan otherwise or when the verification fails), 1 = sequential scan only,
+ * 2 = inject a fault into the block-parallel scan (exercises the verification + fallback; tests only). */
+int sc_ctx_set_permgen_mode(sc_ctx *ctx, int mode);
+/* Completed generator jobs by scan form, how often the block-parallel form failed its verification and the
+ * job was rerun sequentially (0 unless mode 2 injected a fault), and for the block-parallel jobs (failed ones
+ * included) the 32768-draw blocks resolved by a prepared table lookup / computed by the chain workgroup itself. */
+int sc_ctx_permgen_stats(sc_ctx *ctx, int64_t *jobs_parallel, int64_t *jobs_sequential, int64_t *fallbacks,
+                         int64_t *blocks_prepared, int64_t *blocks_chain);
 
 /* ---- A1: kNN graph ------------------------------------------------------------------------
  * Replaces sklearn NearestNeighbors(k+1, "ball_tree").kneighbors + "drop column 0" (AC:393-401),

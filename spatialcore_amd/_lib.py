@@ -32,6 +32,8 @@ SYMBOLS = {
     "sc_ctx_kernel_time": [_P, c_int, POINTER(c_double), POINTER(c_int64)],
     "sc_ctx_reset_timers": [_P],
     "sc_ctx_set_timing": [_P, c_int],
+    "sc_ctx_set_permgen_mode": [_P, c_int],
+    "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
     "sc_knn_2d": [_P, _P, c_int64, c_int, c_int, _P, _P],
     "sc_radius_count_2d": [_P, _P, c_int64, c_double, _P],
@@ -177,6 +179,17 @@ class Context:
 
     def set_timing(self, enabled: bool) -> None:
         _check(self._lib.sc_ctx_set_timing(self._h, int(enabled)))
+
+    def set_permgen_mode(self, mode: int) -> None:
+        """0 automatic, 1 sequential rejection scan only, 2 fault injection (tests). Results never differ."""
+        _check(self._lib.sc_ctx_set_permgen_mode(self._h, int(mode)))
+
+    def permgen_stats(self) -> Tuple[int, int, int, int, int]:
+        """(jobs by the block-parallel scan, jobs by the sequential scan, verification fallbacks,
+        blocks resolved by prepared table lookup, blocks computed by the chain workgroup)."""
+        v = [c_int64(0) for _ in range(5)]
+        _check(self._lib.sc_ctx_permgen_stats(self._h, *[byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def device_mem(self) -> int:
         v = c_int64(0)

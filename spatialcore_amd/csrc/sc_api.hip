@@ -77,6 +77,9 @@ int sc_timer_collect(sc_ctx *c)
     SC_HIP(hipStreamSynchronize(c->stream));
     if (c->stream2) SC_HIP(hipStreamSynchronize(c->stream2));
     if (c->stream3) SC_HIP(hipStreamSynchronize(c->stream3));
+    if (c->stream4) SC_HIP(hipStreamSynchronize(c->stream4));
+    for (hipStream_t sp : c->stream_pg)
+        if (sp) SC_HIP(hipStreamSynchronize(sp));
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         KTimer &t = c->timers[k];
         for (auto &ev : t.pending) {
@@ -149,7 +152,8 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
-                    &c->lee_b, &c->lee_out, &c->lee_pairs, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_bits, &c->pg_enter, &c->pg_sblk};
+                    &c->lee_b, &c->lee_out, &c->lee_pairs, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
+                    &c->pg_desc, &c->pg_tbits, &c->pg_events, &c->pg_hard};
     for (DBuf *b : bufs) b->release(&c->mem);
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         for (auto &ev : c->timers[k].pending) {
@@ -163,6 +167,12 @@ int sc_ctx_destroy(sc_ctx *c)
     }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    for (hipStream_t sp : c->stream_pg)
+        if (sp) (void)hipStreamDestroy(sp);
+    if (c->stream_score) (void)hipStreamDestroy(c->stream_score);
+    for (hipEvent_t e : c->pg_ev)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SC_OK;
@@ -200,6 +210,26 @@ int sc_ctx_set_timing(sc_ctx *c, int enabled)
 {
     SC_REQUIRE(c, SC_ERR_INVALID, "null context");
     c->timing = enabled != 0;
+    return SC_OK;
+}
+
+int sc_ctx_set_permgen_mode(sc_ctx *c, int mode)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_REQUIRE(mode >= 0 && mode <= 2, SC_ERR_INVALID, "sc_ctx_set_permgen_mode: mode %d not in {0, 1, 2}", mode);
+    c->pg_mode = mode;
+    return SC_OK;
+}
+
+int sc_ctx_permgen_stats(sc_ctx *c, int64_t *jobs_parallel, int64_t *jobs_sequential, int64_t *fallbacks,
+                         int64_t *blocks_prepared, int64_t *blocks_chain)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    if (jobs_parallel) *jobs_parallel = c->pg_jobs_parallel;
+    if (jobs_sequential) *jobs_sequential = c->pg_jobs_sequential;
+    if (fallbacks) *fallbacks = c->pg_fallbacks;
+    if (blocks_prepared) *blocks_prepared = c->pg_blocks_prepared;
+    if (blocks_chain) *blocks_chain = c->pg_blocks_chain;
     return SC_OK;
 }
 

@@ -60,6 +60,13 @@ struct sc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // fused permutation/Moran pipeline: rejection scan runs ahead here
     hipStream_t stream3 = nullptr;  // ... and the Fisher-Yates swaps of the scanned chunk here
+    hipStream_t stream4 = nullptr;  // ... alternating with this one
+    hipStream_t stream_score = nullptr;  // scoring stream of the fused pipeline: every CU but the few left to the generator
+    hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
+    hipEvent_t pg_ev[33] = {};        // rings of events between the preparation and the chain launches + start marker
+    int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
+    int64_t pg_jobs_parallel = 0, pg_jobs_sequential = 0, pg_fallbacks = 0;  // generator jobs by scan form
+    int64_t pg_blocks_prepared = 0, pg_blocks_chain = 0;  // block-parallel jobs: blocks resolved by table lookup / by the chain workgroup
     int64_t mem = 0;  // bytes allocated through DBuf
     bool timing = true;
     KTimer timers[SC_K_COUNT_];
@@ -103,6 +110,7 @@ struct sc_ctx {
     bool perm_bijective = false;   // the active table is known to hold true permutations
     bool perm_checked = false;     // ... or was checked and is not
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
+    DBuf pg_desc, pg_tbits, pg_events, pg_hard;  // block-parallel scan: per-block descriptors + gap-transfer tables (ring), hard flags
 
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
@@ -131,7 +139,13 @@ struct PermJob {
     double draws_per_perm = 0; // expectation
     int64_t p_done = 0;        // permutations covered by the scan launches so far
     int64_t chunk_no = 0;
+    bool phi = false;          // block-parallel scan in use
+    uint64_t B_done = 0;       // blocks covered by the chain launches so far
+    uint64_t unit_start[8] = {};  // first block of the last launch units (ring)
+    int64_t unit_no = 0;
 };
+#define SC_PERMGEN_RETRY 1000  // internal: the block-parallel scan failed its verification, rerun sequentially
+bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);
 int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s);
 int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s);

@@ -812,61 +812,78 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
-extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
-                               int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+#ifndef PIPE_FIRST
+#define PIPE_FIRST 32        // permutations of the first pipeline chunk
+#endif
+#ifndef PIPE_LAST
+#define PIPE_LAST 64         // ... of the last one (0: none in particular)
+#endif
+#ifndef PIPE_SWAP_STREAMS
+#define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
+#endif
+
+static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
+                             int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
 {
     SC_REQUIRE(state6, SC_ERR_INVALID, "sc_moran_seeded: null state");
     SC_TRY(moran_check(c, n_perm, I_out));
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
     const int64_t n = c->e_n;
     SC_TRY(sc_perm_alloc(c, n, n_perm));
-    if (!c->stream2) SC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream2) {  // the generator chain is the critical path: highest priority
+        int prio_lo = 0, prio_hi = 0;
+        SC_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        SC_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
+    }
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    if (!c->stream4) SC_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
     // allocations first (hipMalloc synchronises the device), then the two streams run freely
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
     SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
-    // chunk schedule: a short first chunk so that scoring starts early, then PERM_CHUNK each
+    // chunk schedule: a short first chunk so that scoring starts early, PERM_CHUNK each in the middle, a short
+    // last chunk (the step ends with the swaps and the scoring of the last chunk after the scan is done)
     std::vector<int64_t> bounds;
     bounds.push_back(0);
-    {
-        int64_t p = 0;
-        const int64_t first = n_perm > 2 * PERM_CHUNK ? PERM_CHUNK / 4 : PERM_CHUNK;
-        while (p < n_perm) {
-            int64_t step = (p == 0) ? first : (p == first && first < PERM_CHUNK ? PERM_CHUNK - first : PERM_CHUNK);
-            p = p + step < n_perm ? p + step : n_perm;
-            bounds.push_back(p);
-        }
+    if (n_perm > 3 * PERM_CHUNK) {
+        const int64_t last = PIPE_LAST, rest = (n_perm - last - PIPE_FIRST) % PERM_CHUNK;
+        int64_t p = PIPE_FIRST + (rest < PERM_CHUNK / 2 ? rest : 0);  // a small remainder joins the first chunk
+        bounds.push_back(p);
+        if (rest >= PERM_CHUNK / 2) { p += rest; bounds.push_back(p); }
+        for (; p < n_perm - last; ) { p += PERM_CHUNK; bounds.push_back(p); }
+        if (last > 0) bounds.push_back(n_perm);
+    } else {
+        for (int64_t p = PERM_CHUNK; p < n_perm; p += PERM_CHUNK) bounds.push_back(p);
+        bounds.push_back(n_perm);
     }
     const int64_t chunks = (int64_t)bounds.size() - 1;
-    // stream2: scan(0) scan(1) ...      stream3: swaps(k) after scan(k)      stream: score(k) after swaps(k)
+    // stream2: scan(0) scan(1) ...   stream3/4: swaps(k) + inverse(k) after scan(k)   stream: score(k) after swaps(k)
     std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
     PermJob job;
-    int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
-    // the whole generator side is enqueued first: it depends on nothing else and is the longest chain
-    for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
+    auto generate = [&](int64_t k) -> int {
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
-        rc = permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2);
-        if (rc == SC_OK && (hipEventCreateWithFlags(&scanned, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&swapped, hipEventDisableTiming) != hipSuccess ||
-                            hipEventRecord(scanned, c->stream2) != hipSuccess ||
-                            hipStreamWaitEvent(c->stream3, scanned, 0) != hipSuccess)) {
-            sc_set_error("sc_moran_seeded: event plumbing failed");
-            rc = SC_ERR_HIP;
-        }
-        if (rc == SC_OK) rc = permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], c->stream3);
+        hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
+        SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2));
+        SC_HIP(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
+        SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
+        SC_HIP(hipEventRecord(scanned, c->stream2));
+        SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
+        SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
         // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
-        if (rc == SC_OK) rc = invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], c->stream3);
-        if (rc == SC_OK && hipEventRecord(swapped, c->stream3) != hipSuccess) {
-            sc_set_error("sc_moran_seeded: event plumbing failed");
-            rc = SC_ERR_HIP;
-        }
-    }
-    // observed statistic, lag, graph moments (host-blocking in places) overlap the first scan chunk
+        SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
+        SC_HIP(hipEventRecord(swapped, sw));
+        return SC_OK;
+    };
+    int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
+    // The generator is the longest chain and depends on nothing else: its first chunk is enqueued first, then the
+    // observed statistic / lag / graph moments (host-blocking in places), then chunk k + 1 ahead of the scoring of
+    // chunk k, so that neither side waits for the host to enqueue the other (a chunk is some 250 API calls).
+    if (rc == SC_OK) rc = generate(0);
     if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
     c->perm_bijective = true;  // device-generated rows are permutations by construction
     const bool use32 = c->x32_exact;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
-        if (hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
+        if (k + 1 < chunks) rc = generate(k + 1);
+        if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
         }
@@ -874,6 +891,9 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     }
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);
+    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+    for (hipStream_t sp : c->stream_pg)
+        if (sp) (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : ev)
         if (e) (void)hipEventDestroy(e);
@@ -881,6 +901,57 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     SC_TRY(permgen_finish(c, &job, state6));
     c->p_count = n_perm;
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+}
+
+#ifndef SCORE_RESERVED_CUS
+#define SCORE_RESERVED_CUS 8
+#endif
+// SCORE_RESERVED_CUS: compute units the scoring stream leaves to the generator's many short launches
+
+// The scoring kernel fills every CU it may use with workgroups that live for milliseconds; the block-parallel
+// generator is a chain of sub-millisecond launches that must not queue behind them.  While it is in use, scoring
+// runs on a stream whose CU mask leaves a few CUs out; the generator streams may use the whole chip.
+static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
+                                int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+{
+    hipStream_t main_stream = c->stream;
+    if (c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n)) {
+        if (!c->stream_score) {
+            hipDeviceProp_t prop;
+            SC_HIP(hipGetDeviceProperties(&prop, c->device));
+            const int cus = prop.multiProcessorCount;
+            std::vector<uint32_t> mask((size_t)((cus + 31) / 32), 0u);
+            for (int k = SCORE_RESERVED_CUS; k < cus; ++k) mask[(size_t)(k / 32)] |= 1u << (k % 32);
+            SC_HIP(hipExtStreamCreateWithCUMask(&c->stream_score, (uint32_t)mask.size(), mask.data()));
+            // the swaps and the inverse tables of the pipeline stay off the generator's CUs as well
+            for (hipStream_t *sw : {&c->stream3, &c->stream4}) {
+                if (*sw) { SC_HIP(hipStreamSynchronize(*sw)); SC_HIP(hipStreamDestroy(*sw)); *sw = nullptr; }
+                SC_HIP(hipExtStreamCreateWithCUMask(sw, (uint32_t)mask.size(), mask.data()));
+            }
+        }
+        SC_HIP(hipStreamSynchronize(main_stream));
+        c->stream = c->stream_score;
+    }
+    const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+    if (c->stream != main_stream) {
+        (void)hipStreamSynchronize(c->stream);
+        c->stream = main_stream;
+    }
+    return rc;
+}
+
+extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
+                               int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "sc_moran_seeded: null context");
+    int rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+    if (rc == SC_PERMGEN_RETRY) {  // the block-parallel scan failed its verification: nothing was returned yet
+        const int mode = c->pg_mode;
+        c->pg_mode = 1;
+        rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+        c->pg_mode = mode;
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -222,14 +222,98 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     return x;
 }
 
+// Expected number of accepted steps after q draws, starting with `rem` steps left in the permutation (mean
+// field, closed form per mask band: in a band with top = mask + 1 the threshold decays like exp(-q / top)).
+// Only the first guess of the in-block fixed point; follows the acceptance rate through band changes and
+// permutation ends, where a constant rate is off by thousands of steps.
+__device__ __forceinline__ uint32_t expected_steps(uint32_t rem, float q, uint32_t M)
+{
+    float i = (float)rem, acc = 0.f;
+    for (int guard = 0; guard < 64 && q > 0.f; ++guard) {
+        uint32_t ii = (uint32_t)i;
+        if (ii == 0) { i = (float)M; ii = M; }
+        const uint32_t m = mask_of(ii);
+        const float top = (float)m + 1.f, lo = (float)((m >> 1) + 1);
+        const float need = top * __logf((i + 1.f) / lo);  // draws to leave the band
+        if (need <= q) { q -= need; acc += i - lo + 1.f; i = lo - 1.f; }
+        else { const float inew = (i + 1.f) * __expf(-q / top) - 1.f; acc += i - inew; q = 0.f; }
+    }
+    return (uint32_t)(acc + 0.5f);
+}
+
+struct BlockShared {
+    uint32_t wsum[SCAN_THREADS / 64];
+    uint32_t wchg[2][SCAN_THREADS / 64];
+};
+
+// The exact result of ONE block of SCAN_BLOCK draws entered with S_block completed steps, by the whole
+// workgroup: every thread ends with its accept mask (r.bits), its entering count (excl = accepted steps of
+// the block in front of it) and the block's accept count.  Fixed point on the entering counts: a thread
+// recomputes only when its cached result is not provably the result for its new entering count; a thread
+// with the right entering count produces the right count, so the correct prefix grows every round.
+// Returns 1 if the iteration cap was hit (cannot happen: the prefix grows by at least one thread a round).
+__device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], uint64_t S_block,
+                                                 uint32_t rem_block, uint32_t M, uint32_t top_mask, uint64_t total_steps, BlockShared &sh,
+                                                 uint32_t &parity, ScanRes &r, uint32_t &excl, uint32_t &total_cnt)
+{
+    // rem_block = M - S_block % M, the steps left in the current permutation (callers carry it along: a
+    // 64-bit modulo per block by every wavefront costs more than a fifth of the block)
+    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const uint64_t left = total_steps - S_block;
+    const uint32_t limit = left > 0xffffffffULL ? 0xffffffffu : (uint32_t)left;
+    // first guess of the entering count: the expected count (any guess converges; a good one saves rounds)
+    scan_thread(u, expected_steps(rem_block, (float)(tau * SCAN_D), M), rem_block, M, top_mask, limit, r);
+    excl = 0; total_cnt = 0;
+    for (int iter = 0;; ++iter) {
+        const uint32_t incl = wave_inclusive_scan(r.cnt);
+        if (lane == 63) sh.wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+            const uint32_t t = sh.wsum[w];
+            before += (w < (int)wave) ? t : 0u;
+            all += t;
+        }
+        excl = before + incl - r.cnt;
+        total_cnt = all;
+        const bool stale = !scan_still_valid(r, excl, M, limit);
+        const bool wave_stale = __any(stale);
+        if (lane == 0) sh.wchg[parity][wave] = wave_stale ? 1u : 0u;
+        __syncthreads();
+        uint32_t changed = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) changed |= sh.wchg[parity][w];
+        parity ^= 1u;
+#ifdef PHI_PROFILE
+        if (!changed) return -(iter + 1);
+#else
+        if (!changed) return 0;
+#endif
+        if (wave_stale) {
+            if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
+        }
+        if (iter > SCAN_THREADS + 8) return 1;
+    }
+}
+
+// steps left in the current permutation after t more steps
+__device__ __forceinline__ uint32_t rem_advance(uint32_t rem, uint32_t t, uint32_t M)
+{
+    if (t >= rem) { t = (t - rem) % M; rem = M; }
+    return rem - t;
+}
+
 // Per processed block the scan leaves: sblk[b] = steps completed before the block, and per thread
 // acc_bits[b*SCAN_THREADS + tau], enter[b*SCAN_THREADS + tau] (accepted steps of the block in front of the thread).
 // k_expand turns these into J with the whole chip; one CU cannot store 4 bytes per step fast enough.
 //
-// st[0] = steps completed so far, st[1] = next block to process, st[2] = sticky failure flag,
+// st[0] = steps completed so far, st[1] = next block to process, st[2] = sticky failure flags,
 // st[3] = number of raw draws consumed when the job's last step completed.
 // A launch processes WHOLE blocks while fewer than S_target steps are complete (the last block may
 // run past the target; only the end of the job, total_steps, stops mid-block).
+// This is the sequential form of the scan: every block is entered with the exact state its predecessor
+// left.  It is the whole generator for short permutations and the fallback of the block-parallel form below.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restrict__ raw, uint64_t n_blocks,
                                                        uint32_t n, uint64_t S_target, uint64_t total_steps,
                                                        bits_t *__restrict__ acc_bits,
@@ -237,15 +321,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restric
                                                        unsigned long long *__restrict__ sblk,
                                                        unsigned long long *__restrict__ st)
 {
-    __shared__ uint32_t wsum[SCAN_THREADS / 64];
-    __shared__ uint32_t wchg[2][SCAN_THREADS / 64];
+    __shared__ BlockShared sh;
     static_assert(SCAN_THREADS % 64 == 0 && SCAN_D % 4 == 0 && SCAN_D <= 64, "scan geometry");
-    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const uint32_t tau = threadIdx.x;
     const uint32_t M = n - 1;
     const uint32_t top_mask = mask_of(M);
     uint64_t S_block = st[0];
     uint64_t b = st[1];
-    uint32_t rem_block = M - (uint32_t)(S_block % M);  // steps left in the current permutation
+    uint32_t rem_block = M - (uint32_t)(S_block % M);
     uint32_t parity = 0;
     int failed = 0;
     uint64_t endpos = 0;
@@ -257,57 +340,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restric
 #pragma unroll
         for (int s = 0; s < SCAN_D; ++s) u[s] = un[s];
         if (b + 1 < n_blocks) scan_load(raw, (b + 1) * SCAN_BLOCK, tau, un);
-        const uint64_t left = total_steps - S_block;
-        const uint32_t limit = left > 0xffffffffULL ? 0xffffffffu : (uint32_t)left;
-        const float p_acc = (float)(rem_block + 1.0) / (float)((double)mask_of(rem_block) + 1.0);
         ScanRes r;
-        scan_thread(u, (uint32_t)((float)(tau * SCAN_D) * p_acc), rem_block, M, top_mask, limit, r);
-        uint32_t excl = 0, total_cnt = 0;
-        // fixed point on the entering counts: a thread recomputes only when its cached result is
-        // not provably the result for its new entering count
-        for (int iter = 0;; ++iter) {
-            const uint32_t incl = wave_inclusive_scan(r.cnt);
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-#pragma unroll
-            for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-                const uint32_t t = wsum[w];
-                before += (w < (int)wave) ? t : 0u;
-                all += t;
-            }
-            excl = before + incl - r.cnt;
-            total_cnt = all;
-            const bool stale = !scan_still_valid(r, excl, M, limit);
-            const bool wave_stale = __any(stale);
-            if (lane == 0) wchg[parity][wave] = wave_stale ? 1u : 0u;
-            __syncthreads();
-            uint32_t changed = 0;
-#pragma unroll
-            for (int w = 0; w < SCAN_THREADS / 64; ++w) changed |= wchg[parity][w];
-            parity ^= 1u;
-            if (!changed) break;
-            if (wave_stale) {
-                if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
-            }
-            if (iter > SCAN_THREADS + 8) { failed = 1; break; }
+        uint32_t excl, total_cnt;
+        if (block_fixed_point(u, S_block, rem_block, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) {
+            failed = 1;
+            break;
         }
         acc_bits[b * SCAN_THREADS + tau] = r.bits;
         enter[b * SCAN_THREADS + tau] = excl;
         if (tau == 0) sblk[b] = S_block;
         if (r.end) endpos = b * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
         S_block += total_cnt;
-        {   // steps left in the current permutation after total_cnt more steps
-            uint32_t t = total_cnt;
-            if (t >= rem_block) { t = (t - rem_block) % M; rem_block = M; }
-            rem_block -= t;
-        }
+        rem_block = rem_advance(rem_block, total_cnt, M);
     }
     if (endpos) st[3] = endpos;  // exactly one thread of one launch sees the job's last step
     if (tau == 0) {
         st[0] = S_block;
         st[1] = b;
-        if (failed) st[2] = 1;
+        if (failed) st[2] = st[2] | 1ull;
     }
 }
 
@@ -348,6 +398,456 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1 block-parallel: the same exact scan with the per-block work spread over the chip
+//
+// The only thing block b needs from its predecessors is ONE number, the state S_b (completed steps) it
+// is entered with.  S_b is known in advance up to a random-walk error (sigma ~ 0.5 sqrt(draws) since the
+// last exactly known state), so the chip prepares every block of a unit in parallel for a WINDOW of
+// entry states around a guess G_b (k_phi_events + k_phi_tbuild), a single workgroup then chains the exact states through
+// the prepared blocks (k_chain), and the chip finally recomputes every block from its now known exact
+// entry state and checks S_b + count_b == S_{b+1} (k_block_exact): the result is exact by induction or
+// a failure flag is raised (then the caller reruns the sequential form).
+//
+// Preparation of block b ("gap transfer").  Let the BASE trajectory enter with G_b and a second one with
+// G_b + g (gap g, |g| <= w).  As long as both stay inside one permutation and one mask band, a draw with
+// masked value v at a position where the base threshold is t is decided differently only when
+//   g > 0 (second is ahead, its threshold is t - g):  base accepts, second rejects  <=>  g > t - v       (>= 0)
+//   g < 0 (second is behind, threshold t + |g|):      base rejects, second accepts  <=>  |g| > v - t - 1 (>= 0)
+// and each such event shrinks |g| by one.  The map entry gap -> exit gap is therefore monotone with unit
+// steps, and it is represented per side by the set of increments d-1 -> d that survive: start with w set
+// bits, and for every event of slack s (in draw order) clear the set bit of rank s if it exists.  The exit
+// gap of entry gap d is the number of set bits among the first d.  Blocks in which some trajectory of the
+// window crosses a mask band, a permutation end or the job end ("hard" blocks, about a fifth at n = 1M),
+// or that hold too many events, are not prepared; the chain workgroup computes them itself from the exact
+// entry state, exactly like the sequential scan.
+// ------------------------------------------------------------------------------------------------
+
+#define PHI_W 16384               // window bits per side
+#define PHI_WORDS (PHI_W / 64)
+#define PHI_MAX_EV 2048           // events per side a prepared block may hold
+#define PHI_UNIT 160              // blocks per launch unit
+#ifndef PHI_AHEAD
+#define PHI_AHEAD 3               // units prepared ahead of the chain (their guesses use a state PHI_AHEAD + 1 units old)
+#endif
+#define PHI_RING 1024             // table ring slots (> PHI_AHEAD + 2 units)
+#define PHI_STREAMS 4             // preparation streams (units rotate over them)
+#define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
+
+struct PhiDesc {
+    unsigned long long G;  // guessed entry state of the block
+    uint32_t cnt;          // accepts of the base trajectory
+    uint32_t i_in;         // steps left in G's permutation (M - G % M)
+    uint16_t w_pos;        // entry states G + d, 0 <= d <= w_pos, are covered (trajectories ahead of the base)
+    uint16_t w_neg;        // entry states G - d, 0 <= d <= w_neg, are covered (trajectories behind the base)
+    uint16_t n_pos, n_neg; // events per side
+    uint32_t prepared;     // 0: the chain computes this block itself
+    uint32_t pad_;
+};
+
+// Expected state after dq more draws from state S (mean-field, closed form per mask band).  Only a guess:
+// exactness never depends on it.
+__device__ static unsigned long long phi_expect(unsigned long long S, double dq, uint32_t M, double dpp,
+                                                unsigned long long total)
+{
+    int phase = 0;
+    for (int guard = 0; guard < 256 && dq > 0.0 && S < total; ++guard) {
+        const uint32_t done = (uint32_t)(S % M);
+        if (done == 0 && phase == 0) {  // at a permutation boundary: skip whole permutations
+            const double k = floor(dq / dpp);
+            if (k >= 1.0) { S += (unsigned long long)k * M; dq -= k * dpp; }
+            phase = 1;
+            continue;
+        }
+        const uint32_t i = M - done, m = mask_of(i), lo = (m >> 1) + 1;  // band: i in [lo, m]
+        const double top = (double)m + 1.0;
+        const double need = top * log(((double)i + 1.0) / (double)lo);  // draws to leave the band
+        if (need <= dq) { dq -= need; S += (unsigned long long)(i - lo + 1); }
+        else { const double inew = ((double)i + 1.0) * exp(-dq / top) - 1.0; S += (unsigned long long)((double)i - inew + 0.5); dq = 0.0; }
+    }
+    return S < total ? S : total;
+}
+
+__device__ __forceinline__ uint32_t select64(uint64_t x, uint32_t r)  // position of the set bit of rank r < popc(x)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const uint32_t c = (uint32_t)__popcll((x >> pos) & ((1ull << sh) - 1ull));
+        if (r >= c) { r -= c; pos += sh; }
+    }
+    return pos;
+}
+
+// One wavefront builds the surviving-increment bitset of one side (lane l holds bits [256 l, 256 l + 256)).
+__device__ __forceinline__ void phi_tbuild(const uint16_t *ev, uint32_t nev, uint32_t w, unsigned long long *out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t w0, w1, w2, w3;
+    {
+        const uint32_t base = 256 * lane;
+#define PHI_INIT(k) (w >= base + 64 * (k) + 64 ? ~0ull : (w > base + 64 * (k) ? ((1ull << (w - base - 64 * (k))) - 1ull) : 0ull))
+        w0 = PHI_INIT(0); w1 = PHI_INIT(1); w2 = PHI_INIT(2); w3 = PHI_INIT(3);
+#undef PHI_INIT
+    }
+    uint32_t cnt = (uint32_t)(__popcll(w0) + __popcll(w1) + __popcll(w2) + __popcll(w3));
+    uint32_t pre = wave_inclusive_scan(cnt);
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+    for (uint32_t e0 = 0; e0 < nev; e0 += 64) {
+        const uint32_t mine = e0 + lane < nev ? ev[e0 + lane] : 0xffffu;  // 64 events per (coalesced) load
+        const uint32_t nb = nev - e0 < 64 ? nev - e0 : 64;
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)j);
+            if (s >= total) continue;  // no trajectory of the window has a gap above s any more
+            const bool own = (pre - cnt <= s) && (s < pre);
+            const uint32_t L = (uint32_t)__builtin_ctzll(__ballot(own));
+            if (lane == L) {
+                uint32_t r = s - (pre - cnt);
+                const uint32_t c0 = (uint32_t)__popcll(w0), c1 = (uint32_t)__popcll(w1), c2 = (uint32_t)__popcll(w2);
+                if (r < c0) w0 &= ~(1ull << select64(w0, r));
+                else if (r < c0 + c1) w1 &= ~(1ull << select64(w1, r - c0));
+                else if (r < c0 + c1 + c2) w2 &= ~(1ull << select64(w2, r - c0 - c1));
+                else w3 &= ~(1ull << select64(w3, r - c0 - c1 - c2));
+                cnt -= 1;
+            }
+            pre -= (lane >= L) ? 1u : 0u;
+            total -= 1;
+        }
+    }
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + 4 * lane);
+    o[0] = make_ulonglong2(w0, w1);
+    o[1] = make_ulonglong2(w2, w3);
+}
+
+// exit gap of entry gap idx (<= w) on one side: set bits among the first idx (wave 0 only, all lanes)
+__device__ __forceinline__ uint32_t phi_lookup(const unsigned long long *tb, uint32_t idx)
+{
+    const uint32_t lane = threadIdx.x & 63, base = 256 * lane;
+    uint32_t t = 0;
+    if (idx > base) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(tb + 4 * lane);
+        const ulonglong2 a = src[0], b = src[1];
+        const uint64_t wd[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = base + 64 * k;
+            if (idx >= lo + 64) t += (uint32_t)__popcll(wd[k]);
+            else if (idx > lo) t += (uint32_t)__popcll(wd[k] & ((1ull << (idx - lo)) - 1ull));
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
+}
+
+// Prepare blocks [b0, b1), part 1: one workgroup per block finds the base trajectory from the guess G_b and
+// writes the events of both sides (slacks, in draw order).  The guess comes from the exact state at ref_block
+// (PHI_AHEAD + 1 units back), the window from the distance to it.
+__global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__restrict__ raw, uint32_t n,
+                                                             uint64_t total_steps, double dpp, uint64_t b0,
+                                                             uint64_t b1, uint64_t ref_block,
+                                                             const unsigned long long *__restrict__ sblk,
+                                                             PhiDesc *__restrict__ desc,
+                                                             uint16_t *__restrict__ events)
+{
+    __shared__ BlockShared sh;
+    __shared__ unsigned long long shG;
+    __shared__ uint32_t shw, shi;
+    __shared__ uint32_t wpk[SCAN_THREADS / 64];
+    const uint64_t b = b0 + blockIdx.x;
+    if (b >= b1) return;
+    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const uint32_t M = n - 1, top_mask = mask_of(M);
+    const uint64_t slot = b % PHI_RING;
+    if (tau == 0) {
+        const double dq = (double)(b - ref_block) * (double)SCAN_BLOCK;
+        shG = phi_expect(sblk[ref_block], dq, M, dpp, total_steps);
+        // ~4.5 sigma of the random walk since the reference state (sigma = 0.49 sqrt(draws), measured); an entry
+        // state outside the window only costs the chain one computed block
+        const double wd = 2.25 * sqrt(dq) + 64.0;
+        shw = wd < (double)(PHI_W - 1) ? (uint32_t)wd : (uint32_t)(PHI_W - 1);
+        shi = M - (uint32_t)(shG % M);
+    }
+    uint32_t u[SCAN_D];
+    scan_load(raw, b * SCAN_BLOCK, tau, u);
+    __syncthreads();
+    const uint64_t G = shG;
+    const uint32_t w = shw;
+    const uint32_t i_in = shi;
+    bool easy = G + (uint64_t)SCAN_BLOCK + w + 1 < total_steps;
+    ScanRes r;
+    uint32_t excl = 0, total_cnt = 0, parity = 0;
+    uint32_t mask = 0, w_pos = 0, w_neg = 0;
+    if (easy) {  // uniform
+        if (block_fixed_point(u, G, i_in, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) easy = false;
+        mask = mask_of(i_in);
+        const uint32_t cap = mask < M ? mask : M, low = (mask >> 1) + 1;  // the band is [low, mask], capped by M
+        // The base must stay in its band and permutation.  A trajectory that enters d ahead of it stays at
+        // thresholds >= i_out - d, one that enters d behind at thresholds <= i_in + d: each side is covered as
+        // far as its trajectories cannot leave the band either.
+        if (i_in < total_cnt + low) easy = false;
+        else {
+            const uint32_t i_out = i_in - total_cnt;
+            w_pos = w < i_out - low ? w : i_out - low;
+            w_neg = w < cap - i_in ? w : cap - i_in;
+        }
+    }
+    uint32_t totP = 0, totN = 0, offP = 0, offN = 0;
+    if (easy) {
+        uint32_t thr = i_in - excl, np = 0, nn = 0;
+#pragma unroll
+        for (int s = 0; s < SCAN_D; ++s) {
+            const int32_t d = (int32_t)(thr - (u[s] & mask));
+            if (d >= 0) { np += ((uint32_t)d < w_pos) ? 1u : 0u; --thr; }
+            else nn += ((uint32_t)(-d - 1) < w_neg) ? 1u : 0u;
+        }
+        const uint32_t pk = np | (nn << 16);  // both totals <= 32768: no carry between the fields
+        const uint32_t incl = wave_inclusive_scan(pk);
+        if (lane == 63) wpk[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+            const uint32_t t = wpk[k];
+            before += (k < (int)wave) ? t : 0u;
+            all += t;
+        }
+        const uint32_t ex = before + incl - pk;
+        offP = ex & 0xffffu; offN = ex >> 16;
+        totP = all & 0xffffu; totN = all >> 16;
+        if (totP > PHI_MAX_EV || totN > PHI_MAX_EV) easy = false;
+    }
+    PhiDesc d;
+    d.G = G; d.cnt = total_cnt; d.i_in = i_in; d.pad_ = 0;
+    d.w_pos = (uint16_t)w_pos; d.w_neg = (uint16_t)w_neg; d.n_pos = (uint16_t)totP; d.n_neg = (uint16_t)totN;
+    d.prepared = easy ? 1u : 0u;
+    if (tau == 0) desc[slot] = d;
+    if (!easy) return;
+    uint16_t *evP = events + (slot * 2 + 0) * PHI_MAX_EV, *evN = events + (slot * 2 + 1) * PHI_MAX_EV;
+    uint32_t thr = i_in - excl;
+#pragma unroll
+    for (int s = 0; s < SCAN_D; ++s) {
+        const int32_t dd = (int32_t)(thr - (u[s] & mask));
+        if (dd >= 0) { if ((uint32_t)dd < w_pos) evP[offP++] = (uint16_t)dd; --thr; }
+        else if ((uint32_t)(-dd - 1) < w_neg) evN[offN++] = (uint16_t)(-dd - 1);
+    }
+}
+
+// Prepare blocks [b0, b1), part 2: two wavefronts per block turn the event lists into the gap-transfer tables.
+__global__ __launch_bounds__(128) void k_phi_tbuild(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+                                                    const uint16_t *__restrict__ events,
+                                                    unsigned long long *__restrict__ tbits)
+{
+    const uint64_t b = b0 + blockIdx.x;
+    if (b >= b1) return;
+    const uint64_t slot = b % PHI_RING;
+    const PhiDesc d = desc[slot];
+    if (!d.prepared) return;
+    const uint32_t side = threadIdx.x >> 6;
+    phi_tbuild(events + (slot * 2 + side) * PHI_MAX_EV, side ? d.n_neg : d.n_pos, side ? d.w_neg : d.w_pos,
+               tbits + (slot * 2 + side) * PHI_WORDS);
+}
+
+#define PHI_STAGE 24          // prepared blocks of a run whose tables are staged in LDS
+#define PHI_STAGE_WORDS 128   // ... their first 8192 bits per side (entry gaps beyond that read global memory)
+
+// exit gap from a staged table (wave 0 only, all lanes): lane l holds bits [128 l, 128 l + 128)
+__device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_t idx)
+{
+    const uint32_t lane = threadIdx.x & 63, base = 128 * lane;
+    uint32_t t = 0;
+    if (idx > base) {
+        const ulonglong2 a = tl[lane];
+        t = idx >= base + 64 ? (uint32_t)__popcll(a.x) : (uint32_t)__popcll(a.x & ((1ull << (idx - base)) - 1ull));
+        if (idx > base + 64)
+            t += idx >= base + 128 ? (uint32_t)__popcll(a.y) : (uint32_t)__popcll(a.y & ((1ull << (idx - base - 64)) - 1ull));
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
+}
+
+// Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
+// wavefront 0, the others the full in-block fixed point.  While a block is computed, the draws of the next
+// block to compute and the tables of the run of prepared blocks before it are already on their way (registers,
+// then LDS).  Leaves sblk[b] for every block, hardmask[b], and the accept masks / entering counts of the blocks it
+// computed itself.  fault != 0 (testing): corrupt one lookup.
+__global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restrict__ raw, uint64_t n_blocks,
+                                                        uint32_t n, uint64_t total_steps, uint64_t b0, uint64_t b1,
+                                                        uint64_t S_need, const PhiDesc *__restrict__ desc,
+                                                        const unsigned long long *__restrict__ tbits,
+                                                        uint8_t *__restrict__ hardmask, int fault,
+                                                        bits_t *__restrict__ acc_bits, uint32_t *__restrict__ enter,
+                                                        unsigned long long *__restrict__ sblk,
+                                                        unsigned long long *__restrict__ st)
+{
+    __shared__ BlockShared sh;
+    __shared__ PhiDesc dsc[PHI_UNIT];
+    __shared__ uint16_t nxt[PHI_UNIT + 2];  // first block >= i (relative to b0) the chain computes itself
+    __shared__ unsigned long long shS, shB;
+    __shared__ uint32_t shRem;
+    __shared__ ulonglong2 tl[PHI_STAGE * PHI_STAGE_WORDS];  // [staged block][side][64 x 16 B]
+    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const uint32_t M = n - 1, top_mask = mask_of(M);
+    uint64_t S = st[0];
+    if (S >= total_steps || st[1] != b0 || b1 > n_blocks || b1 - b0 > PHI_UNIT) return;  // job complete (uniform)
+    const uint32_t nb = (uint32_t)(b1 - b0);
+    if (tau < nb) dsc[tau] = desc[(b0 + tau) % PHI_RING];
+    __syncthreads();
+    if (tau <= nb) {
+        uint32_t j = tau;
+        while (j < nb && dsc[j].prepared) ++j;
+        nxt[tau] = (uint16_t)j;
+    }
+    __syncthreads();
+    const ulonglong2 *tb2 = reinterpret_cast<const ulonglong2 *>(tbits);
+    // 16-byte chunk c of a staged run that starts at relative block `first`: block c / 128, side (c % 128) / 64
+#define PHI_STAGE_LOAD(first, len)                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                        \
+        const uint32_t cc = tau + SCAN_THREADS * k;                                                        \
+        treg[k] = make_ulonglong2(0ull, 0ull);                                                             \
+        if (cc < (len) * PHI_STAGE_WORDS) {                                                                \
+            const uint64_t slot = (b0 + (first) + cc / PHI_STAGE_WORDS) % PHI_RING;                        \
+            treg[k] = tb2[((slot * 2 + (cc % PHI_STAGE_WORDS) / 64) * PHI_WORDS) / 2 + (cc % 64)];         \
+        }                                                                                                  \
+    }
+    static_assert(PHI_STAGE * PHI_STAGE_WORDS <= 3 * SCAN_THREADS, "three 16-byte chunks per thread");
+    ulonglong2 treg[3];
+    uint32_t un[SCAN_D];
+    uint32_t rel = 0, h = nxt[0];
+    uint32_t staged = h - rel < PHI_STAGE ? h - rel : PHI_STAGE;
+    PHI_STAGE_LOAD(rel, staged)
+    if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
+    uint32_t parity = 0;
+    int failed = 0;
+    uint64_t endpos = 0;
+    uint32_t n_easy = 0, n_hard = 0;
+    uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
+#ifdef PHI_PROFILE
+    unsigned long long t_easy = 0, t_hard = 0, n_iter = 0, t_mark = wall_clock64();
+#endif
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tau + SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) tl[tau + SCAN_THREADS * k] = treg[k];
+        __syncthreads();
+        if (wave == 0) {  // run through the prepared blocks [rel, h)
+            uint32_t r = rel;
+            uint64_t SS = S;
+            uint32_t rr = rem;
+            while (r < h) {
+                const PhiDesc dd = dsc[r];
+                const int64_t d = (int64_t)SS - (int64_t)dd.G;
+                const uint64_t idx = (uint64_t)(d < 0 ? -d : d);
+                if (idx > (d < 0 ? dd.w_neg : dd.w_pos)) break;  // outside the prepared window: compute the block
+                const uint32_t side = d < 0 ? 1u : 0u;
+                uint32_t T = 0;
+                if (idx) {
+                    if (r - rel < staged && idx <= 64 * PHI_STAGE_WORDS)
+                        T = phi_lookup_lds(tl + ((r - rel) * 2 + side) * 64, (uint32_t)idx);
+                    else
+                        T = phi_lookup(tbits + (((b0 + r) % PHI_RING) * 2 + side) * PHI_WORDS, (uint32_t)idx);
+                }
+                if (lane == 0) { sblk[b0 + r] = SS; hardmask[b0 + r] = 0; }
+                SS = dd.G + dd.cnt + (side ? -(int64_t)T : (int64_t)T);
+                if (fault && n_easy == 0) SS += 1;  // testing: the verification must catch this
+                rr = dd.i_in - (uint32_t)(SS - dd.G);  // no trajectory of the window leaves G's permutation
+                ++n_easy;
+                ++r;
+            }
+            if (lane == 0) { shS = SS; shB = r; shRem = rr; }
+        }
+        __syncthreads();
+#ifdef PHI_PROFILE
+        { const unsigned long long t = wall_clock64(); t_easy += t - t_mark; t_mark = t; }
+#endif
+        S = shS;
+        rem = shRem;
+        const uint32_t x = (uint32_t)shB;  // first block not resolved by lookup: h, or earlier on a window miss
+        if (x >= nb) { rel = nb; break; }
+        uint32_t u[SCAN_D];
+        const uint32_t hN = nxt[x + 1];
+        if (x == h) {
+#pragma unroll
+            for (int q = 0; q < SCAN_D; ++q) u[q] = un[q];
+        } else {
+            scan_load(raw, (b0 + x) * SCAN_BLOCK, tau, u);
+        }
+        // on their way while block x is computed: the tables of the next run and the draws of the block after it
+        staged = hN - (x + 1) < PHI_STAGE ? hN - (x + 1) : PHI_STAGE;
+        PHI_STAGE_LOAD(x + 1, staged)
+        if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
+        ScanRes r;
+        uint32_t excl, total_cnt;
+#ifdef PHI_PROFILE
+        { const int it = block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt);
+          if (it > 0) { failed = 1; rel = x; break; }
+          n_iter += (unsigned long long)(-it);
+          if (tau == 0 && b0 < 130) printf("HB b=%lu rem=%u iters=%d cnt=%u t=%.1f\n", b0 + x, rem, -it, total_cnt, (double)(wall_clock64() - t_mark) * 0.01); }
+#else
+        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; rel = x; break; }
+#endif
+        const uint64_t bx = b0 + x;
+        acc_bits[bx * SCAN_THREADS + tau] = r.bits;
+        enter[bx * SCAN_THREADS + tau] = excl;
+        if (tau == 0) { sblk[bx] = S; hardmask[bx] = 1; }
+        if (r.end) endpos = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
+        S += total_cnt;
+        rem = rem_advance(rem, total_cnt, M);
+        ++n_hard;
+#ifdef PHI_PROFILE
+        { const unsigned long long t = wall_clock64(); t_hard += t - t_mark; t_mark = t; }
+#endif
+        rel = x + 1;
+        h = hN;
+        if (S >= total_steps) break;
+    }
+#undef PHI_STAGE_LOAD
+    if (endpos) st[3] = endpos;
+    if (tau == 0) {
+        const uint64_t b = b0 + rel;
+        st[0] = S;
+        st[1] = b;
+        st[4] += n_easy;  // wavefront 0 counted them
+        st[5] += n_hard;
+#ifdef PHI_PROFILE
+        st[6] += t_easy; st[7] += (t_hard << 20) | 0; atomicAdd(st + 6, 0ull);
+        printf("chain unit b0=%lu easy %u hard %u  t_easy %.1f us  t_hard %.1f us  iters %llu\n", b0, n_easy, n_hard, t_easy * 0.01, t_hard * 0.01, n_iter);
+#endif
+        sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
+        unsigned long long f = st[2];
+        if (failed) f |= 1ull;
+        if (S < S_need && S < total_steps) f |= 2ull;  // the blocks granted to this chunk did not complete it
+        st[2] = f;
+    }
+}
+
+// Recompute every prepared block of range [range[0], range[1]) from its exact entry state (whole chip) and
+// verify the chain: S_b + count_b must be the entry state of block b + 1.
+__global__ __launch_bounds__(SCAN_THREADS) void k_block_exact(const uint32_t *__restrict__ raw, uint32_t n,
+                                                              uint64_t total_steps,
+                                                              const unsigned long long *__restrict__ range,
+                                                              const uint8_t *__restrict__ hardmask,
+                                                              bits_t *__restrict__ acc_bits,
+                                                              uint32_t *__restrict__ enter,
+                                                              const unsigned long long *__restrict__ sblk,
+                                                              unsigned long long *__restrict__ st)
+{
+    __shared__ BlockShared sh;
+    __shared__ uint32_t shrem;
+    const uint64_t b = range[0] + blockIdx.x;
+    if (b >= range[1] || hardmask[b]) return;
+    const uint32_t tau = threadIdx.x;
+    const uint32_t M = n - 1, top_mask = mask_of(M);
+    const uint64_t S = sblk[b];
+    if (tau == 0) shrem = M - (uint32_t)(S % M);
+    uint32_t u[SCAN_D];
+    scan_load(raw, b * SCAN_BLOCK, tau, u);
+    __syncthreads();
+    ScanRes r;
+    uint32_t excl, total_cnt, parity = 0;
+    const int failed = block_fixed_point(u, S, shrem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0;
+    acc_bits[b * SCAN_THREADS + tau] = r.bits;
+    enter[b * SCAN_THREADS + tau] = excl;
+    if (tau == 0 && (failed || r.end || S + total_cnt != sblk[b + 1])) atomicOr(st + 2, 4ull);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,6 +917,8 @@ static double expected_draws_per_perm(int64_t n)
     return e;
 }
 
+bool permgen_is_block_parallel(const sc_ctx *c, int64_t n) { return c->pg_mode != 1 && n >= PHI_MIN_N; }
+
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s)
 {
     job->n = n;
@@ -441,14 +943,29 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     SC_TRY(c->pg_J.ensure(sizeof(int32_t) * (size_t)job->total_steps, &c->mem));
     SC_TRY(c->pg_bits.ensure(sizeof(bits_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
     SC_TRY(c->pg_enter.ensure(sizeof(uint32_t) * (size_t)(n_blocks * SCAN_THREADS), &c->mem));
-    SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)n_blocks, &c->mem));
-    // pg_out: [0..3] scan state, then one {first block, end block} pair per chunk for k_expand
+    SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)(n_blocks + 1), &c->mem));
+    job->phi = permgen_is_block_parallel(c, n);
+    job->B_done = 0; job->unit_no = 0;
+    if (job->phi) {
+        SC_TRY(c->pg_desc.ensure(sizeof(PhiDesc) * (size_t)PHI_RING, &c->mem));
+        SC_TRY(c->pg_tbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
+        SC_TRY(c->pg_events.ensure(sizeof(uint16_t) * (size_t)PHI_RING * 2 * PHI_MAX_EV, &c->mem));
+        SC_TRY(c->pg_hard.ensure((size_t)n_blocks + 1, &c->mem));
+        int prio_lo = 0, prio_hi = 0;
+        SC_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // the generator is the critical path of its callers
+        for (hipStream_t &sp : c->stream_pg)
+            if (!sp) SC_HIP(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio_hi));
+        for (hipEvent_t &e : c->pg_ev)
+            if (!e) SC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // pg_out: [0..3] scan state, [4] prepared blocks used, [5] blocks computed by the chain, then one
+    // {first block, end block} pair per chunk for k_expand
     const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK) + 2;  // the fused pipeline splits its first chunk
-    SC_TRY(c->pg_out.ensure(sizeof(unsigned long long) * (size_t)(4 + 2 * (chunks + 1)), &c->mem));
+    SC_TRY(c->pg_out.ensure(sizeof(unsigned long long) * (size_t)(8 + 2 * (chunks + 1)), &c->mem));
     job->chunk_no = 0;
     // A generator that starts with a buffered 32-bit half: that half is the first draw of the
     // stream.  It is consumed here, so that raw draw 0 is always the low half of output 0.
-    unsigned long long st0[4] = {0, 0, 0, 0};
+    unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (job->h) {
         uint32_t mask = (uint32_t)M;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
@@ -460,6 +977,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         }
     }
     SC_HIP(hipMemcpyAsync(c->pg_out.p, st0, sizeof(st0), hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(c->pg_sblk.p, st0, sizeof(unsigned long long), hipMemcpyHostToDevice, s));  // state at block 0
     SC_HIP(hipStreamSynchronize(s));  // st0 / j0 are stack variables
     const Affine jb = lcg_pow(inc, SCAN_BLOCK / 2);
     const uint64_t threads = ((n_blocks + RAW_BLOCKS - 1) / RAW_BLOCKS) * (uint64_t)(SCAN_THREADS * SCAN_GROUPS);
@@ -467,6 +985,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
                        job->inc_hi, job->inc_lo, n_blocks, (uint64_t)(jb.mult >> 64), (uint64_t)jb.mult,
                        (uint64_t)(jb.plus >> 64), (uint64_t)jb.plus, c->pg_raw.as<uint32_t>());
     SC_HIP(hipGetLastError());
+    if (job->phi) SC_HIP(hipEventRecord(c->pg_ev[32], s));  // the preparation streams start after the raw stream
     return SC_OK;
 }
 
@@ -477,11 +996,53 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
     if (job->trivial) return SC_OK;
     const uint64_t n_blocks = job->hi / SCAN_BLOCK;
     unsigned long long *st = c->pg_out.as<unsigned long long>();
-    unsigned long long *range = st + 4 + 2 * job->chunk_no;
+    unsigned long long *range = st + 8 + 2 * job->chunk_no;
     // range[0] = first block of this launch (= st[1] now), range[1] = st[1] afterwards
     SC_HIP(hipMemcpyAsync(range, st + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     const uint64_t target = (uint64_t)p1 * (uint64_t)(job->n - 1);
-    {
+    uint64_t phi_first = 0, phi_end = 0;
+    if (job->phi) {
+        // Blocks granted to this chunk: the expected draws of permutations [0, p1) + ~10 sigma + one block
+        // (k_chain raises a flag if they do not complete the chunk); the last chunk takes all blocks.
+        const double need = (double)p1 * job->draws_per_perm + 9000.0 * sqrt((double)p1) + (double)SCAN_BLOCK;
+        uint64_t B_end = (uint64_t)(need / SCAN_BLOCK) + 1;
+        if (B_end > n_blocks || p1 >= job->n_perm) B_end = n_blocks;
+        phi_first = job->B_done;
+        phi_end = B_end;
+        KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
+        while (job->B_done < B_end) {
+            const uint64_t b0 = job->B_done;
+            const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
+            const int64_t u = job->unit_no;
+            hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
+            hipEvent_t ev_prep = c->pg_ev[(size_t)(u % 16)], ev_chain = c->pg_ev[(size_t)(16 + u % 16)];
+            // The guess of unit u uses the exact state at the start of unit u - PHI_AHEAD, which chain(u - PHI_AHEAD - 1)
+            // leaves; that launch also is the last reader of the ring slots unit u overwrites.
+            const int64_t dep = u - PHI_AHEAD - 1;
+            const uint64_t ref = u >= PHI_AHEAD ? job->unit_start[(size_t)((u - PHI_AHEAD) % 8)] : 0;
+            if (dep >= 0) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[(size_t)(16 + dep % 16)], 0));
+            else SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
+            hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
+                               c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0, b1,
+                               ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
+                               c->pg_events.as<uint16_t>());
+            hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
+                               c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
+                               c->pg_tbits.as<unsigned long long>());
+            SC_HIP(hipEventRecord(ev_prep, sp));
+            SC_HIP(hipStreamWaitEvent(s, ev_prep, 0));
+            hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
+                               (uint32_t)job->n, job->total_steps, b0, b1, b1 == B_end ? target : 0ull,
+                               c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(),
+                               c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
+                               c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
+            SC_HIP(hipEventRecord(ev_chain, s));
+            job->unit_start[(size_t)(u % 8)] = b0;
+            job->B_done = b1;
+            job->unit_no = u + 1;
+        }
+        SC_HIP(hipGetLastError());
+    } else {
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
                            (uint32_t)job->n, target, job->total_steps, c->pg_bits.as<bits_t>(),
@@ -490,7 +1051,16 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
     SC_HIP(hipMemcpyAsync(range + 1, st + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     // blocks this launch can have covered: the chunk's expected draws + 1 % + 2 blocks
     const double chunk_perms = (double)(p1 - job->p_done);
-    const uint64_t max_blocks = (uint64_t)(chunk_perms * job->draws_per_perm * 1.01 / SCAN_BLOCK) + 3;
+    uint64_t max_blocks = (uint64_t)(chunk_perms * job->draws_per_perm * 1.01 / SCAN_BLOCK) + 3;
+    if (job->phi) {
+        max_blocks = phi_end - phi_first;
+        if (max_blocks == 0) max_blocks = 1;
+        // the prepared blocks again, from their exact entry states, on the whole chip + verification of the chain
+        KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
+        hipLaunchKernelGGL(k_block_exact, dim3((unsigned)max_blocks), dim3(SCAN_THREADS), 0, s,
+                           c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, range, c->pg_hard.as<uint8_t>(),
+                           c->pg_bits.as<bits_t>(), c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
+    }
     hipLaunchKernelGGL(k_expand, dim3((unsigned)(max_blocks * SCAN_THREADS / 256)), dim3(256), 0, s,
                        c->pg_raw.as<uint32_t>(), c->pg_bits.as<bits_t>(), c->pg_enter.as<uint32_t>(),
                        c->pg_sblk.as<unsigned long long>(), range, (uint32_t)job->n, job->total_steps,
@@ -515,9 +1085,16 @@ int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStrea
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
 {
     if (job->trivial) return SC_OK;
-    unsigned long long st[4];
+    unsigned long long st[8];
     SC_HIP(hipMemcpy(st, c->pg_out.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (job->phi) { c->pg_blocks_prepared += (int64_t)st[4]; c->pg_blocks_chain += (int64_t)st[5]; }
+    if (job->phi && st[2] != 0) {  // verification of the block-parallel scan failed: the caller reruns sequentially
+        c->pg_fallbacks += 1;
+        sc_set_error("sc_perm_generate: block-parallel scan failed its verification (flags %llu)", st[2]);
+        return SC_PERMGEN_RETRY;
+    }
     SC_REQUIRE(st[2] == 0, SC_ERR_STATE, "sc_perm_generate: rejection scan did not converge");
+    (job->phi ? c->pg_jobs_parallel : c->pg_jobs_sequential) += 1;
     SC_REQUIRE(st[0] == job->total_steps, SC_ERR_STATE,
                "sc_perm_generate: raw stream exhausted after %llu of %llu steps", st[0],
                (unsigned long long)job->total_steps);
@@ -539,7 +1116,7 @@ int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
     return SC_OK;
 }
 
-int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm)
+static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm)
 {
     PermJob job;
     SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream));
@@ -549,5 +1126,19 @@ int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_pe
     }
     SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
+    for (hipStream_t sp : c->stream_pg)
+        if (sp) SC_HIP(hipStreamSynchronize(sp));
     return permgen_finish(c, &job, state6);
+}
+
+int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm)
+{
+    int rc = perm_generate_once(c, state6, n, n_perm);
+    if (rc == SC_PERMGEN_RETRY) {  // state6 is only written on success: rerun with the sequential scan
+        const int mode = c->pg_mode;
+        c->pg_mode = 1;
+        rc = perm_generate_once(c, state6, n, n_perm);
+        c->pg_mode = mode;
+    }
+    return rc;
 }

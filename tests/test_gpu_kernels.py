@@ -96,6 +96,39 @@ def test_device_permutation_stream_is_numpy_exact(ctx, oracle, seed, n, P):
     np.testing.assert_array_equal(words, wwords2)
 
 
+@pytest.mark.parametrize("seed,n,P", [(4, 131072, 5), (8, 140001, 300), (15, 300007, 140), (16, 2500000, 4)])
+def test_block_parallel_scan_modes_agree_with_numpy(ctx, oracle, seed, n, P):
+    """n >= 131072 runs the block-parallel rejection scan (prepared gap-transfer tables + chain + on-device
+    verification).  Mode 0 (automatic), 1 (sequential scan) and 2 (injected fault -> verification must catch it
+    and the call falls back) all return numpy's table and final state, over several pipeline chunks."""
+    from spatialcore_amd._lib import rng_state_words, perm_numpy_host
+
+    wh = rng_state_words(np.random.default_rng(seed))
+    want = perm_numpy_host(wh, n, P)
+    rows = sorted(set([0, 1, P // 2, P - 2, P - 1]))
+    try:
+        for mode in (0, 1, 2):
+            ctx.set_permgen_mode(mode)
+            before = ctx.permgen_stats()
+            w = rng_state_words(np.random.default_rng(seed))
+            got = ctx.generate_permutations(w, n, P, fetch=True)
+            par, seq, fb, prepared, chained = (a - b for a, b in zip(ctx.permgen_stats(), before))
+            if mode == 0:
+                had_prepared = prepared > 0      # n = 131072: every block holds a band crossing, nothing to corrupt
+                assert chained > 0
+            # mode 0: the block-parallel form ran and passed its verification; 2: it was caught and redone
+            want_stats = {0: (1, 0, 0), 1: (0, 1, 0), 2: (0, 1, 1) if had_prepared else (1, 0, 0)}[mode]
+            assert (par, seq, fb) == want_stats, (mode, par, seq, fb, prepared, chained)
+            for r in rows:
+                np.testing.assert_array_equal(got[r], want[r], err_msg=f"mode {mode} row {r}")
+            assert (got.astype(np.int64).sum(axis=1) == n * (n - 1) // 2).all()
+            np.testing.assert_array_equal(w, wh, err_msg=f"mode {mode} final state")
+    finally:
+        ctx.set_permgen_mode(0)
+    with pytest.raises(ValueError):
+        ctx.set_permgen_mode(3)
+
+
 def test_device_permutation_stream_golden_and_midword(ctx):
     """numpy's own known answers (tests/golden/rng_kat.npz), incl. a generator that starts with a
     buffered 32-bit half."""
