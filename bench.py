@@ -213,7 +213,7 @@ def main() -> None:
                          "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and perm_launches else None,
                          "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": perm_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "breakdown_ms_per_step": {"perm_scan_1wg_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
+            "breakdown_ms_per_step": {"perm_scan_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
                                       "moran_perm_kernel": perm_ms / args.steps,
                                       "lag_kernel": lag_ms / args.steps, "knn_kernel": knn_ms / args.steps},
         }

@@ -65,6 +65,7 @@ struct sc_ctx {
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
     hipEvent_t pg_ev[33] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
+    int pg_ahead = 1;                 // launch units the preparation runs ahead of the chain (callers that share the chip raise it)
     int64_t pg_jobs_parallel = 0, pg_jobs_sequential = 0, pg_fallbacks = 0;  // generator jobs by scan form
     int64_t pg_blocks_prepared = 0, pg_blocks_chain = 0;  // block-parallel jobs: blocks resolved by table lookup / by the chain workgroup
     int64_t mem = 0;  // bytes allocated through DBuf
@@ -143,6 +144,7 @@ struct PermJob {
     uint64_t B_done = 0;       // blocks covered by the chain launches so far
     uint64_t unit_start[8] = {};  // first block of the last launch units (ring)
     int64_t unit_no = 0;
+    int ahead = 1;             // units prepared ahead of the chain
 };
 #define SC_PERMGEN_RETRY 1000  // internal: the block-parallel scan failed its verification, rerun sequentially
 bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes

@@ -932,7 +932,10 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
         SC_HIP(hipStreamSynchronize(main_stream));
         c->stream = c->stream_score;
     }
+    const int ahead = c->pg_ahead;
+    c->pg_ahead = 3;  // the preparation launches wait for CUs the scoring workgroups hold for milliseconds
     const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+    c->pg_ahead = ahead;
     if (c->stream != main_stream) {
         (void)hipStreamSynchronize(c->stream);
         c->stream = main_stream;

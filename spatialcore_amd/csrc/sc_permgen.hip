@@ -153,7 +153,8 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     r.c_used = c_in; r.i0 = i0; r.mask = mask; r.end = 0;
     // fast path: neither a mask change, nor the end of a permutation, nor the end of the job can
     // happen within SCAN_D accepts
-    if (i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit) {
+    const bool fast = i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit;
+    if (fast) {
         uint32_t thr = i0, gap = 0xffffffffu;
         bits_t bits = 0;
 #pragma unroll
@@ -166,22 +167,29 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
             thr -= acc;
         }
         r.cnt = i0 - thr; r.bits = bits; r.gap = gap; r.fast = 1;
-        return;
     }
-    uint32_t i = i0, off = c_in, cnt = 0;
+    if (!__any(!fast)) return;  // a wavefront-uniform branch: the straight-line code below must not be merged into every pass
+    if (fast) return;
+    // general path, branch-free: the band / permutation bookkeeping is evaluated for every draw (it is the
+    // identity unless the draw was accepted), so a wavefront with a single such thread pays ~13 plain ALU
+    // operations per draw instead of a divergent branch tree
+    uint32_t i = i0, off = c_in, end = 0;
     bits_t bits = 0;
 #pragma unroll
     for (int s = 0; s < SCAN_D; ++s) {
         const uint32_t v = u[s] & mask;
-        const bool acc = off < limit && v <= i;
-        if (acc) {
-            bits |= (bits_t)1 << s;
-            ++off; ++cnt; --i;
-            if (off == limit) r.end = (uint32_t)s + 1;
-            if (i == 0) { i = M; mask = top_mask; }
-            else if (i <= (mask >> 1)) mask >>= 1;
-        }
+        const uint32_t acc = ((off < limit) & (v <= i)) ? 1u : 0u;
+        bits |= (bits_t)acc << s;
+        off += acc;
+        i -= acc;
+        end = (acc & (off == limit ? 1u : 0u)) ? (uint32_t)s + 1 : end;
+        const bool wrap = i == 0;                 // the permutation is complete: the next one starts at M
+        const uint32_t half = mask >> 1;
+        mask = wrap ? top_mask : (i <= half ? half : mask);
+        i = wrap ? M : i;
     }
+    const uint32_t cnt = off - c_in;
+    r.end = end;
     r.cnt = cnt; r.bits = bits; r.gap = 0; r.fast = 0;
 }
 
@@ -241,6 +249,18 @@ __device__ __forceinline__ uint32_t expected_steps(uint32_t rem, float q, uint32
     return (uint32_t)(acc + 0.5f);
 }
 
+#ifdef PHI_PROFILE
+__device__ unsigned long long g_prof[8];  // rounds, stale threads, stale waves
+#endif
+
+#ifdef PHI_PROFILE
+// accumulate the wall-clock ticks (10 ns) since the previous stamp into g_prof[k] (wave 0 of the chain kernel)
+#define PROF_T(k) if (gridDim.x == 1 && threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_prof[k] += t_ - prof_last; prof_last = t_; }
+__device__ unsigned long long prof_last;
+#else
+#define PROF_T(k)
+#endif
+
 struct BlockShared {
     uint32_t wsum[SCAN_THREADS / 64];
     uint32_t wchg[2][SCAN_THREADS / 64];
@@ -265,6 +285,7 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
     scan_thread(u, expected_steps(rem_block, (float)(tau * SCAN_D), M), rem_block, M, top_mask, limit, r);
     excl = 0; total_cnt = 0;
     for (int iter = 0;; ++iter) {
+        PROF_T(3)
         const uint32_t incl = wave_inclusive_scan(r.cnt);
         if (lane == 63) sh.wsum[wave] = incl;
         __syncthreads();
@@ -277,14 +298,22 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         }
         excl = before + incl - r.cnt;
         total_cnt = all;
+        PROF_T(4)
         const bool stale = !scan_still_valid(r, excl, M, limit);
         const bool wave_stale = __any(stale);
+#ifdef PHI_PROFILE
+        if (gridDim.x == 1) {
+            const unsigned long long sb = __ballot(stale);
+            if (lane == 0) { atomicAdd(&g_prof[1], (unsigned long long)__popcll(sb)); atomicAdd(&g_prof[2], wave_stale ? 1ull : 0ull); if (wave == 0) atomicAdd(&g_prof[0], 1ull); }
+        }
+#endif
         if (lane == 0) sh.wchg[parity][wave] = wave_stale ? 1u : 0u;
         __syncthreads();
         uint32_t changed = 0;
 #pragma unroll
         for (int w = 0; w < SCAN_THREADS / 64; ++w) changed |= sh.wchg[parity][w];
         parity ^= 1u;
+        PROF_T(5)
 #ifdef PHI_PROFILE
         if (!changed) return -(iter + 1);
 #else
@@ -293,6 +322,7 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         if (wave_stale) {
             if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
         }
+        PROF_T(6)
         if (iter > SCAN_THREADS + 8) return 1;
     }
 }
@@ -429,10 +459,10 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_WORDS (PHI_W / 64)
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
 #define PHI_UNIT 160              // blocks per launch unit
-#ifndef PHI_AHEAD
-#define PHI_AHEAD 3               // units prepared ahead of the chain (their guesses use a state PHI_AHEAD + 1 units old)
-#endif
-#define PHI_RING 1024             // table ring slots (> PHI_AHEAD + 2 units)
+#define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
+                                  // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
+                                  // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
+#define PHI_RING 1024             // table ring slots (> PHI_AHEAD_MAX + 2 units)
 #define PHI_STREAMS 4             // preparation streams (units rotate over them)
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
 
@@ -542,7 +572,7 @@ __device__ __forceinline__ uint32_t phi_lookup(const unsigned long long *tb, uin
 
 // Prepare blocks [b0, b1), part 1: one workgroup per block finds the base trajectory from the guess G_b and
 // writes the events of both sides (slacks, in draw order).  The guess comes from the exact state at ref_block
-// (PHI_AHEAD + 1 units back), the window from the distance to it.
+// (ahead + 1 units back), the window from the distance to it.
 __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__restrict__ raw, uint32_t n,
                                                              uint64_t total_steps, double dpp, uint64_t b0,
                                                              uint64_t b1, uint64_t ref_block,
@@ -810,6 +840,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         st[5] += n_hard;
 #ifdef PHI_PROFILE
         st[6] += t_easy; st[7] += (t_hard << 20) | 0; atomicAdd(st + 6, 0ull);
+        if (b0 % 1600 == 0) printf("PROF rounds %llu stale threads %llu stale waves %llu | us: outside %.0f scan+bar1 %.0f valid+bar2 %.0f recompute %.0f\n", g_prof[0], g_prof[1], g_prof[2], g_prof[3]*0.01, g_prof[4]*0.01, g_prof[5]*0.01, g_prof[6]*0.01);
         printf("chain unit b0=%lu easy %u hard %u  t_easy %.1f us  t_hard %.1f us  iters %llu\n", b0, n_easy, n_hard, t_easy * 0.01, t_hard * 0.01, n_iter);
 #endif
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
@@ -902,6 +933,79 @@ __global__ __launch_bounds__(64) void k_apply_swaps(const int32_t *__restrict__ 
     }
 }
 
+// The same rule with a whole workgroup per permutation: SW_T consecutive steps per round.  Two steps of a round
+// touch a common slot only if a later step's own slot i_t is an earlier step's target (j_m == i_t, found by index
+// arithmetic since the i are consecutive) or two steps share a target (j_m == j_l, found with an LDS hash table
+// keyed by the target: CAS insert with linear probing, minimum step index per key).  The longest prefix without
+// such a pair is applied in parallel; the round trip to L2 that bounds a round is paid once per ~SW_T steps.
+#define SW_T 512
+#ifndef SWAPS_WG_MIN_N
+#define SWAPS_WG_MIN_N 65536  // shorter permutations: conflicts are frequent, one wavefront per permutation is enough
+#endif
+#define SW_HASH 2048
+
+__global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
+                                                         int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
+{
+    __shared__ uint32_t hkey[SW_HASH], hmin[SW_HASH];
+    __shared__ uint32_t first_conf[2];
+    const int64_t p = p0 + blockIdx.x;
+    if (p >= n_perm) return;
+    const uint32_t l = threadIdx.x;
+    const uint32_t M = n - 1;
+    int32_t *A = perm + p * pstride;
+    const int32_t *Jp = J + p * (int64_t)M;
+    for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x;
+    if (l < 2) first_conf[l] = SW_T;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int64_t i_top = (int64_t)n - 1;
+    uint32_t round = 0;
+    while (i_top >= 1) {
+        const int64_t i = i_top - l;
+        const bool valid = i >= 1;
+        int32_t j = valid ? Jp[(int64_t)M - i] : -1;
+        if (valid && (uint32_t)j > (uint32_t)i) j = (int32_t)i;  // never index outside [0, i], whatever J holds
+        int32_t a_i = 0, a_j = 0;
+        if (valid) {  // L1 is bypassed: the values the previous round stored are in L2 (vmcnt wait + barrier)
+            a_i = __hip_atomic_load(&A[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a_j = __hip_atomic_load(&A[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < SW_HASH / SW_T; ++k) { hkey[l + SW_T * k] = 0xffffffffu; hmin[l + SW_T * k] = 0xffffffffu; }
+        __syncthreads();
+        uint32_t *fc = &first_conf[round & 1];
+        uint32_t h = 0;
+        if (valid) {
+            const int64_t t = i_top - j;  // the step whose own slot is j (t >= l; t == l is a self swap)
+            if (t < SW_T && t != (int64_t)l) atomicMin(fc, (uint32_t)t);
+            h = ((uint32_t)j * 2654435761u) >> 21;
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, (uint32_t)j);
+                if (old == 0xffffffffu || old == (uint32_t)j) break;
+                h = (h + 1) & (SW_HASH - 1);
+            }
+            atomicMin(&hmin[h], l);
+        }
+        __syncthreads();
+        if (valid && hmin[h] < l) atomicMin(fc, l);
+        if (l == 0) first_conf[(round + 1) & 1] = SW_T;  // next round's cell (nobody touches it this round)
+        __syncthreads();
+        uint32_t count = *fc;
+        const int64_t nvalid = i_top < SW_T ? i_top : SW_T;
+        if ((int64_t)count > nvalid) count = (uint32_t)nvalid;
+        if (l < count) {
+            A[i] = a_j;
+            if (j != (int32_t)i) A[j] = a_i;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        i_top -= count;
+        ++round;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -946,6 +1050,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)(n_blocks + 1), &c->mem));
     job->phi = permgen_is_block_parallel(c, n);
     job->B_done = 0; job->unit_no = 0;
+    job->ahead = c->pg_ahead >= 1 && c->pg_ahead <= PHI_AHEAD_MAX ? c->pg_ahead : 1;
     if (job->phi) {
         SC_TRY(c->pg_desc.ensure(sizeof(PhiDesc) * (size_t)PHI_RING, &c->mem));
         SC_TRY(c->pg_tbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
@@ -1016,10 +1121,10 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
             const int64_t u = job->unit_no;
             hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
             hipEvent_t ev_prep = c->pg_ev[(size_t)(u % 16)], ev_chain = c->pg_ev[(size_t)(16 + u % 16)];
-            // The guess of unit u uses the exact state at the start of unit u - PHI_AHEAD, which chain(u - PHI_AHEAD - 1)
+            // The guess of unit u uses the exact state at the start of unit u - ahead, which chain(u - ahead - 1)
             // leaves; that launch also is the last reader of the ring slots unit u overwrites.
-            const int64_t dep = u - PHI_AHEAD - 1;
-            const uint64_t ref = u >= PHI_AHEAD ? job->unit_start[(size_t)((u - PHI_AHEAD) % 8)] : 0;
+            const int64_t dep = u - job->ahead - 1;
+            const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
             if (dep >= 0) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[(size_t)(16 + dep % 16)], 0));
             else SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
             hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
@@ -1075,8 +1180,12 @@ int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStrea
 {
     if (job->trivial || p1 <= p0) return SC_OK;
     KernelTimerScope ts(c, SC_K_PERM_SWAP, s);
-    hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)(p1 - p0)), dim3(64), 0, s, c->pg_J.as<int32_t>(),
-                       c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    if (job->n >= SWAPS_WG_MIN_N)
+        hipLaunchKernelGGL(k_apply_swaps_wg, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+                           c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    else
+        hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)(p1 - p0)), dim3(64), 0, s, c->pg_J.as<int32_t>(),
+                           c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
     SC_HIP(hipGetLastError());
     return SC_OK;
 }
