@@ -95,6 +95,9 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--source-bits", type=int, default=32, choices=(32, 64),
+                    help="narrowest exact copy of the expression values the permutation kernel may gather "
+                         "(32: float32 raw values, 64: the general fp64 kernel)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code path "
                          "on a 1-GPU box; never a measurement)")
@@ -126,6 +129,7 @@ def main() -> None:
     n, G, P, k = args.cells, args.genes, args.perms, args.k
     coords, X = synth_inputs(n, G, seed=42, gene_offset=rank * G)
     ctx = _lib.Context(local_rank)
+    ctx.set_moran_source_bits(args.source_bits)
     ctx.set_expression(X, np.arange(G))   # inputs resident in HBM before the timed region
 
     gathered = None
@@ -183,12 +187,15 @@ def main() -> None:
         avg_ms = perm_ms / max(perm_launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
         traffic = None
-        kernel_name = "k_moran_perm32"  # float32 expression source (this bench); float64 sources run k_moran_perm
-        tpath = os.path.join(ROOT, "profiles", "moran_perm_pmc_traffic.json")
+        # the synthetic matrix is float32 like an AnnData X: the library gathers the raw float32 values, 32 genes
+        # per row (--source-bits 64 forces the general fp64 kernel)
+        source_bits = ctx.moran_source_bits()
+        kernel_name = {32: "k_moran_perm32", 64: "k_moran_perm"}[source_bits]
+        tpath = os.path.join(ROOT, "profiles", f"{kernel_name}_pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("cells") == n and tj.get("perms") == P:
+            if tj.get("cells") == n and tj.get("perms") == P and tj.get("kernel") == kernel_name:
                 traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": "genes/sec Moran's I (1000 perms, 1M cells, k=15)",
@@ -206,6 +213,7 @@ def main() -> None:
             "config": {"workload": f"{n} cells (uniform 2-D), {G} genes per GPU, k={k} kNN, "
                                    f"{P} numpy-exact permutations, seed={args.seed}"
                                    + (" (BASELINE configs[1])" if (n, G, P, k) == (1_000_000, 500, 1000, 15) else " (non-default size)"),
+                       "expression_source": {32: "float32", 64: "float64"}[source_bits],
                        "cells": n, "genes_per_gpu": G, "genes_total": G * world, "k": k, "perms": P,
                        "parallelism": f"gene-shard x{world}, one all-gather of (I, p)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,6 +61,14 @@ int sc_ctx_reset_timers(sc_ctx *ctx);
 /* Enable/disable per-launch HIP-event timing (default on; events are recorded on the ctx stream). */
 int sc_ctx_set_timing(sc_ctx *ctx, int enabled);
 int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
+/* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values:
+ * float32 when every value is a float32 (32 genes per 128-byte row), else the fp64 tiles (16 genes per row).
+ * z = (double)x - mean is rebuilt in registers, so both give the same z.  min_bits (32 or 64; default 32) forbids the
+ * narrower source; sc_ctx_moran_source_bits reports what the last scoring call used (64 = the general fp64 kernel).
+ * A uint16 source for count data (64 genes per row) was built and measured: only 9 % faster per gene, the kernel then
+ * is bound by the L1 traffic of the streamed lag rows; not kept. */
+int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
+int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
 /* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream
  * (results are identical in every mode): 0 = automatic (block-parallel scan for n >= 131072, verified on the
  * device, sequential scan otherwise or when the verification fails), 1 = sequential scan only,

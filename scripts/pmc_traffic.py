@@ -6,7 +6,7 @@ Usage (on the GPU box, after two separate counter passes of the same command):
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
     python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write k_moran_perm32 gpurun_out/pmc_out
 
-Writes <out>/moran_perm_pmc_traffic.json (read by bench.py for roofline.traffic) and
+Writes <out>/<kernel>_pmc_traffic.json (read by bench.py for roofline.traffic) and
 <out>/pmc_fetch_write_by_kernel.csv. Units and the gfx950 correction follow
 /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts a 128-B request
 made of 16-B-per-lane loads as 64 B, so kernels whose loads are all 16 B per lane are doubled (argument
@@ -79,7 +79,7 @@ def main() -> None:
                   "reads; every load of this kernel is 16 B per lane); the counters are L2 memory-side requests, "
                   "Infinity-Cache hits included",
     }
-    with open(os.path.join(out, "moran_perm_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(out, f"{kernel}_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))
 

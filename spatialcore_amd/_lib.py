@@ -33,6 +33,8 @@ SYMBOLS = {
     "sc_ctx_reset_timers": [_P],
     "sc_ctx_set_timing": [_P, c_int],
     "sc_ctx_set_permgen_mode": [_P, c_int],
+    "sc_ctx_set_moran_source_bits": [_P, c_int],
+    "sc_ctx_moran_source_bits": [_P, _P],
     "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
     "sc_knn_2d": [_P, _P, c_int64, c_int, c_int, _P, _P],
@@ -183,6 +185,16 @@ class Context:
     def set_permgen_mode(self, mode: int) -> None:
         """0 automatic, 1 sequential rejection scan only, 2 fault injection (tests). Results never differ."""
         _check(self._lib.sc_ctx_set_permgen_mode(self._h, int(mode)))
+
+    def set_moran_source_bits(self, min_bits: int) -> None:
+        """Narrowest exact source copy the permutation kernels may gather: 32 (default) or 64."""
+        _check(self._lib.sc_ctx_set_moran_source_bits(self._h, int(min_bits)))
+
+    def moran_source_bits(self) -> int:
+        """Source width the last scoring call gathered: 32 (float32 raw values) or 64 (fp64 kernel)."""
+        v = c_int(0)
+        _check(self._lib.sc_ctx_moran_source_bits(self._h, byref(v)))
+        return v.value
 
     def permgen_stats(self) -> Tuple[int, int, int, int, int]:
         """(jobs by the block-parallel scan, jobs by the sequential scan, verification fallbacks,

@@ -221,6 +221,23 @@ int sc_ctx_set_permgen_mode(sc_ctx *c, int mode)
     return SC_OK;
 }
 
+int sc_ctx_set_moran_source_bits(sc_ctx *c, int min_bits)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_REQUIRE(min_bits == 32 || min_bits == 64, SC_ERR_INVALID, "sc_ctx_set_moran_source_bits: %d not in {32, 64}",
+               min_bits);
+    c->source_bits_min = min_bits;
+    c->x32_valid = false;  // re-evaluated by the next scoring call
+    return SC_OK;
+}
+
+int sc_ctx_moran_source_bits(sc_ctx *c, int *bits)
+{
+    SC_REQUIRE(c && bits, SC_ERR_INVALID, "null pointer");
+    *bits = c->last_source_bits;
+    return SC_OK;
+}
+
 int sc_ctx_permgen_stats(sc_ctx *c, int64_t *jobs_parallel, int64_t *jobs_sequential, int64_t *fallbacks,
                          int64_t *blocks_prepared, int64_t *blocks_chain)
 {

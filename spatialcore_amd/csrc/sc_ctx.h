@@ -62,6 +62,7 @@ struct sc_ctx {
     hipStream_t stream3 = nullptr;  // ... and the Fisher-Yates swaps of the scanned chunk here
     hipStream_t stream4 = nullptr;  // ... alternating with this one
     hipStream_t stream_score = nullptr;  // scoring stream of the fused pipeline: every CU but the few left to the generator
+    bool stream_score_failed = false;    // the runtime refused CU masks: scoring stays on the main stream
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
     hipEvent_t pg_ev[33] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
@@ -100,6 +101,8 @@ struct sc_ctx {
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // [tile32][cell][32] float: the raw values again, when they are float32-exact
     bool x32_valid = false, x32_exact = false;
+    int source_bits_min = 32;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
+    int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene
 

@@ -63,7 +63,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     int64_t tiles = ceil_div64(n_genes, SC_TILE);
     size_t bytes = (size_t)tiles * n * SC_TILE * sizeof(double);
     SC_TRY(c->X.ensure(bytes, &c->mem));
-    size_t gb = (size_t)tiles * SC_TILE * sizeof(double);
+    size_t gb = (size_t)align_up64(tiles, 2) * SC_TILE * sizeof(double);  // the 32-gene kernel reads 32 means
     SC_TRY(c->g_mean.ensure(gb, &c->mem));
     SC_TRY(c->g_var.ensure(gb, &c->mem));
     SC_TRY(c->g_z2.ensure(gb, &c->mem));
@@ -601,18 +601,21 @@ __global__ __launch_bounds__(256) void k_moran_perm32(const float *__restrict__ 
     }
 }
 
-// sims[p0 + p][g0 + slot] = scale[g0 + slot] * sum_s partial[s][p][slot], slot < 32   (ascending s)
-__global__ __launch_bounds__(256) void k_moran_finalize32(const double *__restrict__ partial,
+// sims[p0 + p][32 t + slot] = scale[32 t + slot] * sum_s partial[t][s][p][slot], slot < 32 (ascending s), for every
+// 32-gene tile pair t = blockIdx.y of a chunk in one launch
+__global__ __launch_bounds__(256) void k_moran_finalize32(const double *__restrict__ partial, int64_t tile_stride,
                                                           const double *__restrict__ scale,
                                                           double *__restrict__ sims, int n_perm, int splits,
-                                                          int64_t n_genes, int64_t g0, int64_t g_end, int64_t p0)
+                                                          int64_t n_genes, int64_t p0)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int p = t >> 5, slot = t & 31;
-    if (p >= n_perm || g0 + slot >= g_end) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 5, slot = t & 31;
+    const int64_t g = 32 * (int64_t)blockIdx.y + slot;
+    if (p >= n_perm || g >= n_genes) return;
+    const double *pt = partial + (int64_t)blockIdx.y * tile_stride;
     double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += partial[((int64_t)k * n_perm + p) * 32 + slot];
-    sims[(p0 + p) * n_genes + g0 + slot] = scale[g0 + slot] * s;
+    for (int k = 0; k < splits; ++k) s += pt[((int64_t)k * n_perm + p) * 32 + slot];
+    sims[(p0 + p) * n_genes + g] = scale[g] * s;
 }
 
 static int pick_splits(int64_t n, int n_perm_tiles, int64_t *cells_per_split)
@@ -660,7 +663,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm)
         // partial sums for one chunk of permutations (<= PERM_CHUNK, or all of them in the unfused call)
         int64_t cps = 0;
         int splits = pick_splits(n, 1, &cps);  // upper bound on the split count
-        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * 32, &c->mem));
+        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * 32 * (size_t)((T + 1) / 2), &c->mem));
         if (!c->x32_valid) {  // float32 copy of the raw values for the half-traffic kernel, if that is exact
             const int64_t T32 = (T + 1) / 2;
             SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));
@@ -693,10 +696,16 @@ static int invert_rows(sc_ctx *c, int64_t p0, int64_t p1, hipStream_t s)
 
 // Decide whether the half-traffic kernel may be used for the active table; a table uploaded by the
 // caller is only trusted after checking that every row is a bijection (inverse of the inverse).
-static int moran_choose_path(sc_ctx *c, int64_t n_perm, bool *use32)
+// narrowest exact source the scoring may gather: 32 (float32 raw values), 64 (the fp64 kernel)
+static int moran_source_bits(const sc_ctx *c)
 {
-    *use32 = false;
-    if (n_perm <= 0 || !c->x32_exact) return SC_OK;
+    return c->source_bits_min <= 32 && c->x32_exact ? 32 : 64;
+}
+
+static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
+{
+    *bits = 64;
+    if (n_perm <= 0 || moran_source_bits(c) == 64) return SC_OK;
     SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
     if (!c->perm_bijective && !c->perm_checked) {
         SC_TRY(invert_rows(c, 0, n_perm, c->stream));
@@ -710,13 +719,14 @@ static int moran_choose_path(sc_ctx *c, int64_t n_perm, bool *use32)
         c->perm_checked = true;
         c->perm_bijective = (bad == 0);
     }
-    *use32 = c->perm_bijective;
+    if (c->perm_bijective) *bits = moran_source_bits(c);
     return SC_OK;
 }
 
 // score permutations [p0, p1) of the active table for every gene tile (on the context stream).
-// use32: half-traffic kernel (needs inverse rows [p0, p1); invert_here launches that inversion first).
-static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, bool use32, bool invert_here)
+// bits: 64 = fp64 kernel; 32 = gather the raw float32 values through the inverse permutation (needs inverse rows
+// [p0, p1); invert_here launches that inversion first).
+static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool invert_here)
 {
     const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
     const size_t tile_elems = (size_t)n * SC_TILE;
@@ -725,9 +735,11 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, bool use32, bool 
     const int ptiles = (int)ceil_div64(cnt, MP_PERMS_PER_BLOCK);
     int64_t cps = 0;
     const int splits = pick_splits(n, ptiles, &cps);
-    if (use32) {
+    c->last_source_bits = bits;
+    if (bits == 32) {
         if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
         const int64_t T32 = (T + 1) / 2;
+        const int64_t pt_stride = (int64_t)splits * cnt * 32;  // partial sums of one tile pair
         for (int64_t t = 0; t < T32; ++t) {
             const int64_t ta = 2 * t, tb = 2 * t + 1 < T ? 2 * t + 1 : 2 * t;  // odd tile count: B mirrors A, unused
             {
@@ -736,13 +748,14 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, bool use32, bool 
                                    c->X32.as<float>() + (size_t)t * n * 32, c->Lag.as<double>() + ta * tile_elems,
                                    c->Lag.as<double>() + tb * tile_elems, c->g_mean.as<double>() + ta * SC_TILE,
                                    c->g_mean.as<double>() + tb * SC_TILE, c->inv.as<int32_t>() + p0 * c->p_stride,
-                                   c->partial.as<double>(), n, c->p_stride, cnt, cps);
+                                   c->partial.as<double>() + t * pt_stride, n, c->p_stride, cnt, cps);
             }
-            const int64_t g_hi = (2 * t + 2) * SC_TILE < G ? (2 * t + 2) * SC_TILE : G;  // genes of the tile pair
-            hipLaunchKernelGGL(k_moran_finalize32, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256)), dim3(256), 0,
-                               c->stream, c->partial.as<double>(), c->g_scale.as<double>(), c->sims.as<double>(), cnt,
-                               splits, G, ta * SC_TILE, g_hi, p0);
         }
+        // one reduction launch for all tile pairs of the chunk (between the scoring launches it would serialise
+        // 16 small kernels per chunk on the scoring stream)
+        hipLaunchKernelGGL(k_moran_finalize32, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256), (unsigned)T32),
+                           dim3(256), 0, c->stream, c->partial.as<double>(), pt_stride, c->g_scale.as<double>(),
+                           c->sims.as<double>(), cnt, splits, G, p0);
         SC_HIP(hipGetLastError());
         return SC_OK;
     }
@@ -805,10 +818,10 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1),
                           &c->mem));
-    bool use32 = false;
-    SC_TRY(moran_choose_path(c, n_perm, &use32));
+    int bits = 64;
+    SC_TRY(moran_choose_path(c, n_perm, &bits));
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK)
-        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm, use32, true));
+        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm, bits, true));
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
@@ -830,10 +843,14 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
     const int64_t n = c->e_n;
     SC_TRY(sc_perm_alloc(c, n, n_perm));
-    if (!c->stream2) {  // the generator chain is the critical path: highest priority
+    if (!c->stream2) {  // the generator chain is the critical path: highest priority (plain stream if refused)
         int prio_lo = 0, prio_hi = 0;
-        SC_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        SC_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+            (void)hipGetLastError();
+            c->stream2 = nullptr;
+            SC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        }
     }
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     if (!c->stream4) SC_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
@@ -880,14 +897,14 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     if (rc == SC_OK) rc = generate(0);
     if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
     c->perm_bijective = true;  // device-generated rows are permutations by construction
-    const bool use32 = c->x32_exact;
+    const int bits = moran_source_bits(c);
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
         if (k + 1 < chunks) rc = generate(k + 1);
         if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1], use32, false);
+        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1], bits, false);
     }
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);
@@ -916,21 +933,35 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
 {
     hipStream_t main_stream = c->stream;
     if (c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n)) {
-        if (!c->stream_score) {
+        if (!c->stream_score && !c->stream_score_failed) {
+            // Best effort: without CU masks (unsupported runtime, odd CU count) the pipeline still runs, the generator's
+            // launches just queue behind the scoring workgroups more often.
             hipDeviceProp_t prop;
             SC_HIP(hipGetDeviceProperties(&prop, c->device));
             const int cus = prop.multiProcessorCount;
             std::vector<uint32_t> mask((size_t)((cus + 31) / 32), 0u);
             for (int k = SCORE_RESERVED_CUS; k < cus; ++k) mask[(size_t)(k / 32)] |= 1u << (k % 32);
-            SC_HIP(hipExtStreamCreateWithCUMask(&c->stream_score, (uint32_t)mask.size(), mask.data()));
-            // the swaps and the inverse tables of the pipeline stay off the generator's CUs as well
-            for (hipStream_t *sw : {&c->stream3, &c->stream4}) {
-                if (*sw) { SC_HIP(hipStreamSynchronize(*sw)); SC_HIP(hipStreamDestroy(*sw)); *sw = nullptr; }
-                SC_HIP(hipExtStreamCreateWithCUMask(sw, (uint32_t)mask.size(), mask.data()));
+            hipStream_t score = nullptr, sw3 = nullptr, sw4 = nullptr;
+            const bool ok = cus > 2 * SCORE_RESERVED_CUS &&
+                            hipExtStreamCreateWithCUMask(&score, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+                            hipExtStreamCreateWithCUMask(&sw3, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+                            hipExtStreamCreateWithCUMask(&sw4, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (ok) {
+                // the swaps and the inverse tables of the pipeline stay off the generator's CUs as well
+                for (hipStream_t *sw : {&c->stream3, &c->stream4})
+                    if (*sw) { SC_HIP(hipStreamSynchronize(*sw)); SC_HIP(hipStreamDestroy(*sw)); *sw = nullptr; }
+                c->stream_score = score; c->stream3 = sw3; c->stream4 = sw4;
+            } else {
+                (void)hipGetLastError();
+                for (hipStream_t x : {score, sw3, sw4})
+                    if (x) (void)hipStreamDestroy(x);
+                c->stream_score_failed = true;
             }
         }
-        SC_HIP(hipStreamSynchronize(main_stream));
-        c->stream = c->stream_score;
+        if (c->stream_score) {
+            SC_HIP(hipStreamSynchronize(main_stream));
+            c->stream = c->stream_score;
+        }
     }
     const int ahead = c->pg_ahead;
     c->pg_ahead = 3;  // the preparation launches wait for CUs the scoring workgroups hold for milliseconds

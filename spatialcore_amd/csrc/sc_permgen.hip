@@ -1056,10 +1056,16 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         SC_TRY(c->pg_tbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
         SC_TRY(c->pg_events.ensure(sizeof(uint16_t) * (size_t)PHI_RING * 2 * PHI_MAX_EV, &c->mem));
         SC_TRY(c->pg_hard.ensure((size_t)n_blocks + 1, &c->mem));
-        int prio_lo = 0, prio_hi = 0;
-        SC_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // the generator is the critical path of its callers
-        for (hipStream_t &sp : c->stream_pg)
-            if (!sp) SC_HIP(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio_hi));
+        int prio_lo = 0, prio_hi = 0;  // the generator is the critical path of its callers (plain streams if refused)
+        const bool prio = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
+        for (hipStream_t &sp : c->stream_pg) {
+            if (sp) continue;
+            if (!prio || hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+                (void)hipGetLastError();
+                sp = nullptr;
+                SC_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+            }
+        }
         for (hipEvent_t &e : c->pg_ev)
             if (!e) SC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }

@@ -256,6 +256,41 @@ def test_moran_seeded_pipeline_equals_two_step(ctx, oracle, n, G, P):
     assert_counts_match(one["count_ge"], tab["sims"], tab["I"])
 
 
+@pytest.mark.parametrize("G", [5, 32, 47, 70])
+def test_moran_source_widths_agree(ctx, oracle, G):
+    """The permutation kernels gather the narrowest EXACT copy of the raw values: float32 (32 genes per row) when
+    every value is one, else the fp64 tiles (16).  Both rebuild the same z; the sums run in another order (1e-9)."""
+    from spatialcore_amd._lib import rng_state_words
+
+    n, k, P = 3000, 6, 37
+    coords, X = synth(n, G, 5, dtype=np.float32, sparse_x=False)
+    tab = oracle.morans_i_reference_table(coords, X, list(range(G)), k, P, seed=3)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    out = {}
+    try:
+        for bits in (32, 64):
+            ctx.set_moran_source_bits(bits)
+            ctx.set_expression(X, np.arange(G))
+            w = rng_state_words(np.random.default_rng(3))
+            out[bits] = ctx.moran_seeded(w, P)
+            assert ctx.moran_source_bits() == bits
+        ctx.set_moran_source_bits(32)
+        Xd = X.astype(np.float64) + 1e-9                          # float64 values that are not float32
+        ctx.set_expression(Xd, np.arange(G))
+        ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
+        assert ctx.moran_source_bits() == 64
+    finally:
+        ctx.set_moran_source_bits(32)
+    np.testing.assert_array_equal(out[32]["I"], out[64]["I"])
+    np.testing.assert_allclose(out[32]["sims"], out[64]["sims"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(out[32]["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(out[32]["I"], tab["I"], rtol=1e-9, atol=1e-14)
+    assert_counts_match(out[32]["count_ge"], tab["sims"], tab["I"])
+    with pytest.raises(ValueError):
+        ctx.set_moran_source_bits(16)
+
+
 def test_moran_gene_subset_and_uploaded_perms(ctx, oracle):
     coords, X = synth(4000, 12, 23, dtype=np.float32)
     cols = [7, 2, 11]
