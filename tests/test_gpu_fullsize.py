@@ -45,7 +45,10 @@ def test_permutation_table_1m(big, oracle):
     ctx, _, _ = big
     P = 40
     w = _lib.rng_state_words(np.random.default_rng(0))
+    before = ctx.permgen_stats()
     perms = ctx.generate_permutations(w, N, P, fetch=True)
+    par, seq, fallbacks, prepared, chained = (a - b for a, b in zip(ctx.permgen_stats(), before))
+    assert (par, seq, fallbacks) == (1, 0, 0) and prepared > 3 * chained > 0       # block-parallel scan, verified
     # every row is a permutation of 0..N-1 (checksum of checksums: sum and sum of squares + sort of one row)
     s1 = perms.astype(np.int64).sum(axis=1)
     assert (s1 == N * (N - 1) // 2).all()
@@ -177,6 +180,8 @@ def test_config4_shape_5m_cells_indexing():
         ctx.set_expression(X, np.arange(G))
         w = _lib.rng_state_words(np.random.default_rng(0))
         out = ctx.moran_seeded(w, P)
+        par, seq, fallbacks, prepared, chained = ctx.permgen_stats()
+        assert (par, seq, fallbacks) == (1, 0, 0) and prepared > 10 * chained > 0   # block-parallel scan, verified
         wh = _lib.rng_state_words(np.random.default_rng(0))
         host = _lib.perm_numpy_host(wh, n, P)                     # numpy-exact reference for the whole table
         np.testing.assert_array_equal(w, wh)
