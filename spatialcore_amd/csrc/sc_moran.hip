@@ -825,6 +825,9 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
+#ifndef PIPE_AHEAD
+#define PIPE_AHEAD 3         // launch units the generator's preparation runs ahead of its chain inside the pipeline
+#endif
 #ifndef PIPE_FIRST
 #define PIPE_FIRST 32        // permutations of the first pipeline chunk
 #endif
@@ -964,7 +967,7 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
         }
     }
     const int ahead = c->pg_ahead;
-    c->pg_ahead = 3;  // the preparation launches wait for CUs the scoring workgroups hold for milliseconds
+    c->pg_ahead = PIPE_AHEAD;  // the preparation launches wait for CUs the scoring workgroups hold for milliseconds
     const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
     c->pg_ahead = ahead;
     if (c->stream != main_stream) {

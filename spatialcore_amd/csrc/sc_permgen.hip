@@ -249,18 +249,6 @@ __device__ __forceinline__ uint32_t expected_steps(uint32_t rem, float q, uint32
     return (uint32_t)(acc + 0.5f);
 }
 
-#ifdef PHI_PROFILE
-__device__ unsigned long long g_prof[8];  // rounds, stale threads, stale waves
-#endif
-
-#ifdef PHI_PROFILE
-// accumulate the wall-clock ticks (10 ns) since the previous stamp into g_prof[k] (wave 0 of the chain kernel)
-#define PROF_T(k) if (gridDim.x == 1 && threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_prof[k] += t_ - prof_last; prof_last = t_; }
-__device__ unsigned long long prof_last;
-#else
-#define PROF_T(k)
-#endif
-
 struct BlockShared {
     uint32_t wsum[SCAN_THREADS / 64];
     uint32_t wchg[2][SCAN_THREADS / 64];
@@ -285,7 +273,6 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
     scan_thread(u, expected_steps(rem_block, (float)(tau * SCAN_D), M), rem_block, M, top_mask, limit, r);
     excl = 0; total_cnt = 0;
     for (int iter = 0;; ++iter) {
-        PROF_T(3)
         const uint32_t incl = wave_inclusive_scan(r.cnt);
         if (lane == 63) sh.wsum[wave] = incl;
         __syncthreads();
@@ -298,31 +285,18 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         }
         excl = before + incl - r.cnt;
         total_cnt = all;
-        PROF_T(4)
         const bool stale = !scan_still_valid(r, excl, M, limit);
         const bool wave_stale = __any(stale);
-#ifdef PHI_PROFILE
-        if (gridDim.x == 1) {
-            const unsigned long long sb = __ballot(stale);
-            if (lane == 0) { atomicAdd(&g_prof[1], (unsigned long long)__popcll(sb)); atomicAdd(&g_prof[2], wave_stale ? 1ull : 0ull); if (wave == 0) atomicAdd(&g_prof[0], 1ull); }
-        }
-#endif
         if (lane == 0) sh.wchg[parity][wave] = wave_stale ? 1u : 0u;
         __syncthreads();
         uint32_t changed = 0;
 #pragma unroll
         for (int w = 0; w < SCAN_THREADS / 64; ++w) changed |= sh.wchg[parity][w];
         parity ^= 1u;
-        PROF_T(5)
-#ifdef PHI_PROFILE
-        if (!changed) return -(iter + 1);
-#else
         if (!changed) return 0;
-#endif
         if (wave_stale) {
             if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
         }
-        PROF_T(6)
         if (iter > SCAN_THREADS + 8) return 1;
     }
 }
@@ -458,11 +432,13 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_W 16384               // window bits per side
 #define PHI_WORDS (PHI_W / 64)
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
+#ifndef PHI_UNIT
 #define PHI_UNIT 160              // blocks per launch unit
+#endif
 #define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
                                   // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
                                   // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
-#define PHI_RING 1024             // table ring slots (> PHI_AHEAD_MAX + 2 units)
+#define PHI_RING 2048             // table ring slots (> PHI_AHEAD_MAX + 2 units)
 #define PHI_STREAMS 4             // preparation streams (units rotate over them)
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
 
@@ -751,9 +727,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     uint64_t endpos = 0;
     uint32_t n_easy = 0, n_hard = 0;
     uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
-#ifdef PHI_PROFILE
-    unsigned long long t_easy = 0, t_hard = 0, n_iter = 0, t_mark = wall_clock64();
-#endif
     for (;;) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -786,9 +759,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
             if (lane == 0) { shS = SS; shB = r; shRem = rr; }
         }
         __syncthreads();
-#ifdef PHI_PROFILE
-        { const unsigned long long t = wall_clock64(); t_easy += t - t_mark; t_mark = t; }
-#endif
         S = shS;
         rem = shRem;
         const uint32_t x = (uint32_t)shB;  // first block not resolved by lookup: h, or earlier on a window miss
@@ -807,14 +777,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
         ScanRes r;
         uint32_t excl, total_cnt;
-#ifdef PHI_PROFILE
-        { const int it = block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt);
-          if (it > 0) { failed = 1; rel = x; break; }
-          n_iter += (unsigned long long)(-it);
-          if (tau == 0 && b0 < 130) printf("HB b=%lu rem=%u iters=%d cnt=%u t=%.1f\n", b0 + x, rem, -it, total_cnt, (double)(wall_clock64() - t_mark) * 0.01); }
-#else
         if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; rel = x; break; }
-#endif
         const uint64_t bx = b0 + x;
         acc_bits[bx * SCAN_THREADS + tau] = r.bits;
         enter[bx * SCAN_THREADS + tau] = excl;
@@ -823,9 +786,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         S += total_cnt;
         rem = rem_advance(rem, total_cnt, M);
         ++n_hard;
-#ifdef PHI_PROFILE
-        { const unsigned long long t = wall_clock64(); t_hard += t - t_mark; t_mark = t; }
-#endif
         rel = x + 1;
         h = hN;
         if (S >= total_steps) break;
@@ -838,11 +798,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         st[1] = b;
         st[4] += n_easy;  // wavefront 0 counted them
         st[5] += n_hard;
-#ifdef PHI_PROFILE
-        st[6] += t_easy; st[7] += (t_hard << 20) | 0; atomicAdd(st + 6, 0ull);
-        if (b0 % 1600 == 0) printf("PROF rounds %llu stale threads %llu stale waves %llu | us: outside %.0f scan+bar1 %.0f valid+bar2 %.0f recompute %.0f\n", g_prof[0], g_prof[1], g_prof[2], g_prof[3]*0.01, g_prof[4]*0.01, g_prof[5]*0.01, g_prof[6]*0.01);
-        printf("chain unit b0=%lu easy %u hard %u  t_easy %.1f us  t_hard %.1f us  iters %llu\n", b0, n_easy, n_hard, t_easy * 0.01, t_hard * 0.01, n_iter);
-#endif
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
         unsigned long long f = st[2];
         if (failed) f |= 1ull;
