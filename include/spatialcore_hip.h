@@ -41,8 +41,8 @@ extern "C" {
 #define SC_K_KNN 2
 #define SC_K_PERMGEN 3
 #define SC_K_LEE_PERM 4
-#define SC_K_PERM_SCAN 5 /* rejection scan of the permutation generator (one workgroup) */
-#define SC_K_PERM_SWAP 6 /* Fisher-Yates application, one wavefront per permutation */
+#define SC_K_PERM_SCAN 5 /* rejection scan of the permutation generator (chain of exact block states + verification) */
+#define SC_K_PERM_SWAP 6 /* Fisher-Yates application, one workgroup (or wavefront) per permutation */
 #define SC_K_COUNT_ 8
 
 typedef struct sc_ctx sc_ctx;
@@ -146,8 +146,9 @@ int sc_perm_set(sc_ctx *ctx, const int32_t *perm, int64_t n, int64_t n_perm);
 int sc_moran(sc_ctx *ctx, int64_t n_perm, double *I_out, double *sims_out, int64_t *count_ge_out,
              double *sim_sum_out, double *sim_sumsq_out);
 /* Same result as sc_perm_generate(state6, n_cells, n_perm) followed by sc_moran(n_perm), but the
- * two are pipelined: the generator's rejection scan (one workgroup) runs ahead on a second stream
- * while the rest of the chip applies the swaps and scores the previous chunk of permutations.
+ * two are pipelined: the generator's rejection scan runs ahead on its own streams (a chain of exact block states
+ * on a few CUs the scoring stream leaves free) while the rest of the chip applies the swaps and scores the
+ * previous chunk of permutations.
  * state6 is advanced exactly as n_perm calls of rng.permutation(n_cells) would; the table stays
  * resident as the active permutation table. */
 int sc_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
