@@ -119,6 +119,7 @@ struct sc_ctx {
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
     DBuf lee_a, lee_b, lee_out, lee_pairs;
+    DBuf np_cnt, np_comp, np_leaves, np_leafsum;  // numpy-order column sums: block counts, compacted values, leaf table, leaf sums
 };
 
 struct KernelTimerScope {

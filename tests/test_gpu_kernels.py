@@ -318,6 +318,40 @@ def test_moran_zero_variance_gene_is_nan(ctx, oracle):
     assert np.isfinite(out["I"][[0, 2]]).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_numpy_order_column_sums_large(ctx, dtype):
+    """local_morans_i standardises with float means / sds that must be numpy's own (scipy sparse .mean(axis=0):
+    first stored entry + PAIRWISE sum of the rest).  The device evaluates that summation tree in parallel
+    (compaction, leaves, ordered combine); every z must equal the host's bit for bit, for column populations
+    around every branch of the recursion (0, 1, 2, 7, 8, 9, 128, 129, 130, 1000, half, all)."""
+    from scipy import sparse
+
+    n = 150_001
+    rng = np.random.default_rng(12)
+    pops = [0, 1, 2, 7, 8, 9, 128, 129, 130, 137, 1000, 4097, n // 2, n - 1, n]
+    X = np.zeros((n, len(pops)), dtype=dtype)
+    for g, cnt in enumerate(pops):
+        rows = rng.choice(n, cnt, replace=False)
+        X[rows, g] = (rng.poisson(3.0, cnt) + 1) * (1.0 if g % 2 else 0.37)     # counts and non-integers
+    coords = rng.uniform(0, 4000.0, (n, 2))
+    Xs = sparse.csc_matrix(X)
+    mean = np.asarray(Xs.mean(axis=0)).ravel()                                 # the reference's expressions (AC:79-107)
+    sq_mean = np.asarray(Xs.power(2).mean(axis=0)).ravel()
+    means = mean.astype(np.float32)
+    stds = np.sqrt(sq_mean - mean ** 2).astype(np.float32)
+    zero = stds == 0
+    stds[zero] = 1.0
+    want = (X.astype(np.float32) - means) / stds
+    want[:, zero] = 0.0
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, np.arange(len(pops)))
+    out = ctx.local_moran(n, 0)
+    np.testing.assert_array_equal(out["zero_var"], zero)
+    got = out["z"].copy(); got[:, zero] = 0.0
+    np.testing.assert_array_equal(got, want)
+
+
 def test_lee_vs_reference_golden(ctx, oracle):
     from spatialcore_amd._lib import rng_state_words
 
