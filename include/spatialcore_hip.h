@@ -177,6 +177,16 @@ int sc_lee(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, const int6
  * float32 sd is 0 (AC:825-830; the caller blanks those columns, AC:902-906). */
 int sc_local_moran(sc_ctx *ctx, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
                    float *I_out, int32_t *count_out, uint8_t *zero_var_out);
+/* Per-cell finalisation of the last sc_local_moran on the device (its z / lag / counts stay resident; count_out
+ * above may then be null), replacing the p-value, FDR and quadrant passes of AC:888-934 over (n_cells x n_genes):
+ * sc_local_moran_hist returns hist[g][c] = cells of gene g with permutation count c, c = 0..n_perm, from which the
+ * caller builds per-gene lookup tables with the reference's own expressions (p = float32((c+1)/(P+1)), BH / Bonferroni
+ * adjusted values per level); sc_local_moran_classify applies them: p = p_tab[g][count], p_adj = padj_tab[g][count],
+ * quadrant int8 (AC:219-265: 1 HH, 2 LL, 3 HL, 4 LH by the signs of z and lag; 0 where p_adj >= alpha or
+ * force_ns[g]).  Without permutations the tables / p outputs are null and quadrants come from the signs alone. */
+int sc_local_moran_hist(sc_ctx *ctx, int64_t *hist_out);
+int sc_local_moran_classify(sc_ctx *ctx, const float *p_tab, const float *padj_tab, const uint8_t *force_ns,
+                            float alpha, float *p_out, float *padj_out, int8_t *quadrant_out);
 
 /* ---- N2: Local Lee's L -----------------------------------------------------------------------
  * Replaces the per-pair body of lees_l_local (AC:1373-1413): population-std z-scores of the two

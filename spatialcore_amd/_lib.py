@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional, Tuple
 
 import numpy as np
@@ -55,6 +55,8 @@ SYMBOLS = {
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
+    "sc_local_moran_hist": [_P, _P],
+    "sc_local_moran_classify": [_P, _P, _P, _P, c_float, _P, _P, _P],
     "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
     "sc_nearest_2d": [_P, _P, c_int64, _P, c_int64, _P, _P],
     "sc_pairwise_2d": [_P, _P, c_int64, _P, c_int64, POINTER(c_double), POINTER(c_double)],
@@ -342,16 +344,36 @@ class Context:
         return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
 
     # ---- N1 / N2 ----------------------------------------------------------------------------
-    def local_moran(self, n_cells: int, n_perm: int, perm_row0: int = 0):
+    def local_moran(self, n_cells: int, n_perm: int, perm_row0: int = 0, fetch_counts: bool = True):
         G = self._n_genes
         z = np.empty((n_cells, G), dtype=np.float32)
         lag = np.empty((n_cells, G), dtype=np.float32)
         I = np.empty((n_cells, G), dtype=np.float32)
-        cnt = np.zeros((n_cells, G), dtype=np.int32) if n_perm > 0 else None
+        cnt = np.zeros((n_cells, G), dtype=np.int32) if (n_perm > 0 and fetch_counts) else None
         zero = np.zeros(G, dtype=np.uint8)
         _check(self._lib.sc_local_moran(self._h, int(n_perm), int(perm_row0), _ptr(z), _ptr(lag), _ptr(I), _ptr(cnt),
                                         _ptr(zero)))
         return {"z": z, "lag": lag, "I": I, "count": cnt, "zero_var": zero.astype(bool)}
+
+    def local_moran_hist(self, n_perm: int) -> np.ndarray:
+        """hist[g][c] = cells of gene g whose permutation count is c (of the last local_moran call)."""
+        hist = np.zeros((self._n_genes, n_perm + 1), dtype=np.int64)
+        _check(self._lib.sc_local_moran_hist(self._h, _ptr(hist)))
+        return hist
+
+    def local_moran_classify(self, n_cells: int, p_tab, padj_tab, force_ns, alpha):
+        """Per-cell p, adjusted p (table lookups by permutation count) and LISA quadrants of the last local_moran."""
+        G = self._n_genes
+        with_p = p_tab is not None
+        p = np.empty((n_cells, G), dtype=np.float32) if with_p else None
+        padj = np.empty((n_cells, G), dtype=np.float32) if with_p else None
+        q = np.empty((n_cells, G), dtype=np.int8)
+        pt = _c(p_tab, np.float32) if with_p else None
+        at = _c(padj_tab, np.float32) if with_p else None
+        f = _c(np.asarray(force_ns).astype(np.uint8), np.uint8)
+        _check(self._lib.sc_local_moran_classify(self._h, _ptr(pt), _ptr(at), _ptr(f), c_float(float(np.float32(alpha))),
+                                                 _ptr(p), _ptr(padj), _ptr(q)))
+        return p, padj, q
 
     def lee_local(self, n_cells: int, gene_x: int, gene_y: int, n_perm: int = 0, perm_row0: int = 0):
         zx = np.empty(n_cells, dtype=np.float64)

@@ -119,6 +119,8 @@ struct sc_ctx {
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
     DBuf lee_a, lee_b, lee_out, lee_pairs;
+    bool lm_valid = false;   // z / lag / counts of the last sc_local_moran are still resident
+    int64_t lm_perms = 0;
     DBuf np_cnt, np_comp, np_leaves, np_leafsum;  // numpy-order column sums: block counts, compacted values, leaf table, leaf sums
 };
 

@@ -74,6 +74,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     c->e_tiles = tiles;
     c->x32_valid = false;
     c->x32_exact = false;
+    c->lm_valid = false;
     return SC_OK;
 }
 
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void k_div_sd(double *__restrict__ Z, const do
 // mean, Z = X - mean, z2 = sum Z^2, var = z2 / n
 static int expr_center(sc_ctx *c)
 {
+    c->lm_valid = false;  // Z is about to be rewritten
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "no expression loaded (call sc_expr_set_* first)");
     int64_t n = c->e_n;
     SC_TRY(c->Z.ensure((size_t)c->e_tiles * n * SC_TILE * sizeof(double), &c->mem));
@@ -1461,8 +1463,8 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
     SC_HIP(hipSetDevice(c->device));
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran: no expression loaded");
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran: graph missing or size mismatch");
+    c->lm_valid = false;
     if (n_perm > 0) {
-        SC_REQUIRE(count_out, SC_ERR_INVALID, "sc_local_moran: count_out required when n_perm > 0");
         SC_REQUIRE(c->p_n == c->e_n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
                    "sc_local_moran: needs permutation rows [%lld, %lld) of length %lld", (long long)perm_row0,
                    (long long)(perm_row0 + n_perm), (long long)c->e_n);
@@ -1543,7 +1545,7 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
         SC_HIP(hipMemcpyAsync(o.dst, c->lee_a.p, sizeof(float) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
                               c->stream));
     }
-    if (n_perm > 0) {
+    if (n_perm > 0 && count_out) {
         hipLaunchKernelGGL(k_untile<int32_t>, dim3(gu), dim3(256), 0, c->stream, cnt, c->lee_a.as<int32_t>(), n, G);
         SC_HIP(hipMemcpyAsync(count_out, c->lee_a.p, sizeof(int32_t) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
                               c->stream));
@@ -1551,6 +1553,122 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
     if (zero_var_out)
         SC_HIP(hipMemcpyAsync(zero_var_out, zero, (size_t)G, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->lm_valid = true;  // z / lag / counts stay resident for sc_local_moran_hist / sc_local_moran_classify
+    c->lm_perms = n_perm;
+    return SC_OK;
+}
+
+// hist[gene][c] = cells of the gene with permutation count c (LDS-private per workgroup while 16 genes' worth fits)
+#define LMH_LDS 12288
+__global__ __launch_bounds__(256) void k_lm_hist(const int32_t *__restrict__ cnt, int64_t n, int P1,
+                                                 unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t h[LMH_LDS];
+    const int64_t tile = blockIdx.y;
+    const int32_t *ct = cnt + tile * n * SC_TILE;
+    unsigned long long *ht = hist + tile * SC_TILE * P1;
+    const bool priv = SC_TILE * P1 <= LMH_LDS;
+    if (priv) {
+        for (int k = threadIdx.x; k < SC_TILE * P1; k += 256) h[k] = 0;
+        __syncthreads();
+    }
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n * SC_TILE; t += (int64_t)gridDim.x * 256) {
+        int c = ct[t];
+        c = c < 0 ? 0 : (c >= P1 ? P1 - 1 : c);
+        const int slot = (int)(t & 15);
+        if (priv) atomicAdd(&h[slot * P1 + c], 1u);
+        else atomicAdd(&ht[slot * P1 + c], 1ull);
+    }
+    if (priv) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < SC_TILE * P1; k += 256)
+            if (h[k]) atomicAdd(&ht[k], (unsigned long long)h[k]);
+    }
+}
+
+extern "C" int sc_local_moran_hist(sc_ctx *c, int64_t *hist_out)
+{
+    SC_REQUIRE(c && hist_out, SC_ERR_INVALID, "sc_local_moran_hist: null pointer");
+    SC_REQUIRE(c->lm_valid && c->lm_perms > 0, SC_ERR_STATE, "sc_local_moran_hist: no sc_local_moran result with permutations");
+    SC_HIP(hipSetDevice(c->device));
+    const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
+    const int P1 = (int)c->lm_perms + 1;
+    const size_t tile_f = (size_t)T * n * SC_TILE;
+    const int32_t *cnt = reinterpret_cast<const int32_t *>(c->Lag.as<float>() + tile_f);
+    SC_TRY(c->lee_b.ensure(sizeof(unsigned long long) * (size_t)(T * SC_TILE) * (size_t)P1, &c->mem));
+    SC_HIP(hipMemsetAsync(c->lee_b.p, 0, sizeof(unsigned long long) * (size_t)(T * SC_TILE) * (size_t)P1, c->stream));
+    hipLaunchKernelGGL(k_lm_hist, dim3(256, (unsigned)T), dim3(256), 0, c->stream, cnt, n, P1,
+                       c->lee_b.as<unsigned long long>());
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(hist_out, c->lee_b.p, sizeof(int64_t) * (size_t)G * (size_t)P1, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// p = p_tab[g][count], p_adj = padj_tab[g][count], LISA quadrant (AC:219-265): 1 HH, 2 LL, 3 HL, 4 LH from the signs of
+// z and lag, 0 where p_adj >= alpha or the gene is flagged; row-major outputs
+__global__ __launch_bounds__(256) void k_lm_classify(const float *__restrict__ Z32, const float *__restrict__ Lag32,
+                                                     const int32_t *__restrict__ cnt, int64_t n, int64_t G, int P1,
+                                                     const float *__restrict__ p_tab, const float *__restrict__ padj_tab,
+                                                     const unsigned char *__restrict__ force_ns, float alpha,
+                                                     float *__restrict__ p_out, float *__restrict__ padj_out,
+                                                     signed char *__restrict__ q_out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * G) return;
+    const int64_t i = t / G, g = t - i * G;
+    const int64_t src = (g >> 4) * n * SC_TILE + i * SC_TILE + (g & 15);
+    const float z = Z32[src], lag = Lag32[src];
+    signed char q = 0;
+    if (z > 0.f && lag > 0.f) q = 1;
+    if (z < 0.f && lag < 0.f) q = 2;
+    if (z > 0.f && lag < 0.f) q = 3;
+    if (z < 0.f && lag > 0.f) q = 4;
+    if (P1 > 0) {
+        int c = cnt[src];
+        c = c < 0 ? 0 : (c >= P1 ? P1 - 1 : c);
+        const float pa = padj_tab[g * P1 + c];
+        p_out[t] = p_tab[g * P1 + c];
+        padj_out[t] = pa;
+        if (pa >= alpha) q = 0;
+    }
+    if (force_ns[g]) q = 0;
+    q_out[t] = q;
+}
+
+extern "C" int sc_local_moran_classify(sc_ctx *c, const float *p_tab, const float *padj_tab, const uint8_t *force_ns,
+                                       float alpha, float *p_out, float *padj_out, int8_t *quadrant_out)
+{
+    SC_REQUIRE(c && force_ns && quadrant_out, SC_ERR_INVALID, "sc_local_moran_classify: null pointer");
+    SC_REQUIRE(c->lm_valid, SC_ERR_STATE, "sc_local_moran_classify: no sc_local_moran result");
+    SC_HIP(hipSetDevice(c->device));
+    const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
+    const int P1 = c->lm_perms > 0 ? (int)c->lm_perms + 1 : 0;
+    if (P1 > 0) SC_REQUIRE(p_tab && padj_tab && p_out && padj_out, SC_ERR_INVALID, "sc_local_moran_classify: tables and outputs required with permutations");
+    const size_t tile_f = (size_t)T * n * SC_TILE, cells = (size_t)n * (size_t)G;
+    const float *Z32 = c->Z.as<float>(), *Lag32 = c->Lag.as<float>();
+    const int32_t *cnt = reinterpret_cast<const int32_t *>(Lag32 + tile_f);
+    // device staging: [p | p_adj | quadrant] row-major, tables, flags
+    SC_TRY(c->lee_a.ensure(sizeof(float) * 2 * cells + cells + 64, &c->mem));
+    SC_TRY(c->lee_b.ensure(sizeof(float) * 2 * (size_t)G * (size_t)(P1 > 0 ? P1 : 1) + (size_t)G + 64, &c->mem));
+    float *d_p = c->lee_a.as<float>(), *d_pa = d_p + cells;
+    signed char *d_q = reinterpret_cast<signed char *>(d_pa + cells);
+    float *d_pt = c->lee_b.as<float>(), *d_at = d_pt + (size_t)G * (size_t)(P1 > 0 ? P1 : 1);
+    unsigned char *d_f = reinterpret_cast<unsigned char *>(d_at + (size_t)G * (size_t)(P1 > 0 ? P1 : 1));
+    if (P1 > 0) {
+        SC_HIP(hipMemcpyAsync(d_pt, p_tab, sizeof(float) * (size_t)G * P1, hipMemcpyHostToDevice, c->stream));
+        SC_HIP(hipMemcpyAsync(d_at, padj_tab, sizeof(float) * (size_t)G * P1, hipMemcpyHostToDevice, c->stream));
+    }
+    SC_HIP(hipMemcpyAsync(d_f, force_ns, (size_t)G, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_lm_classify, dim3((unsigned)ceil_div64(n * G, 256)), dim3(256), 0, c->stream, Z32, Lag32, cnt, n,
+                       G, P1, d_pt, d_at, d_f, alpha, d_p, d_pa, d_q);
+    SC_HIP(hipGetLastError());
+    if (P1 > 0) {
+        SC_HIP(hipMemcpyAsync(p_out, d_p, sizeof(float) * cells, hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipMemcpyAsync(padj_out, d_pa, sizeof(float) * cells, hipMemcpyDeviceToHost, c->stream));
+    }
+    SC_HIP(hipMemcpyAsync(quadrant_out, d_q, cells, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }

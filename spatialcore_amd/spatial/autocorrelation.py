@@ -450,6 +450,24 @@ def _bh_from_counts(counts: np.ndarray, n_permutations: int) -> np.ndarray:
     return np.clip(a, 0, 1).astype(np.float32)[counts]
 
 
+def _padj_tables(hist: np.ndarray, n_cells: int, n_permutations: int, method: str) -> np.ndarray:
+    """Adjusted p-value of every permutation-count level, per gene: ``tab[g, c]`` is what the reference's FDR step
+    (AC:132-183 applied per gene at AC:912-920) gives a cell of gene g whose count is c.  ``hist[g, c]`` = number of
+    cells at that level.  Same dtypes as the reference: float32 levels, float32 product, float64 quotient, float32
+    store (see ``_bh_from_counts``, which this vectorises over genes)."""
+    levels = ((np.arange(n_permutations + 1) + 1) / (n_permutations + 1)).astype(np.float32)
+    if method == "none":
+        return np.tile(levels, (hist.shape[0], 1))
+    if method == "bonferroni":
+        return np.tile(np.clip(levels * n_cells, 0, 1).astype(np.float32), (hist.shape[0], 1))
+    last_rank = np.cumsum(hist, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = (levels * np.float32(n_cells)).astype(np.float64)[None, :] / last_rank
+    a[hist == 0] = np.inf
+    a = np.minimum.accumulate(a[:, ::-1], axis=1)[:, ::-1]
+    return np.clip(a, 0, 1).astype(np.float32)
+
+
 def local_morans_i(
     adata,
     genes: Optional[Union[str, List[str]]] = None,
@@ -490,57 +508,80 @@ def local_morans_i(
     _knn_weights_f32(ctx, coords, n_neighbors)
     X = _expression(adata, layer)
 
-    local_I = np.zeros((n_cells, n_genes), dtype=np.float32)
-    z_values = np.zeros((n_cells, n_genes), dtype=np.float32)
-    lag_values = np.zeros((n_cells, n_genes), dtype=np.float32)
-    p_values = np.ones((n_cells, n_genes), dtype=np.float32)
-    counts = np.full((n_cells, n_genes), n_permutations, dtype=np.int32)
-    zero_var_mask = np.zeros(n_genes, dtype=bool)
-
     words = _lib.rng_state_words(np.random.default_rng(seed))
     n_batches = (n_genes + batch_size - 1) // batch_size
     logger.info(f"Processing {n_genes} genes in {n_batches} batches")
+    levels = ((np.arange(n_permutations + 1) + 1) / (n_permutations + 1)).astype(np.float32)
+    single = n_batches == 1
+
+    def alloc(dtype, fill=None):
+        if single:
+            return None                      # the batch's own arrays become the outputs
+        a = np.empty((n_cells, n_genes), dtype=dtype)
+        if fill is not None:
+            a.fill(fill)
+        return a
+
+    local_I, z_values, lag_values = alloc(np.float32), alloc(np.float32), alloc(np.float32)
+    p_values = alloc(np.float32) if n_permutations > 0 else None
+    p_adj = alloc(np.float32) if n_permutations > 0 else None
+    quadrants = alloc(np.int8)
+    zero_var_mask = np.zeros(n_genes, dtype=bool)
+
+    def put(dst, src, b0, b1, inv):
+        if inv is not None:
+            src = src[:, inv]
+        if single:
+            return np.ascontiguousarray(src)
+        dst[:, b0:b1] = src
+        return dst
+
     for batch_idx in range(n_batches):
         b0, b1 = batch_idx * batch_size, min((batch_idx + 1) * batch_size, n_genes)
         logger.debug(f"Processing batch {batch_idx + 1}/{n_batches}")
         cols, inv = np.unique(gene_indices[b0:b1], return_inverse=True)
+        if inv.size == cols.size and np.array_equal(inv, np.arange(cols.size)):
+            inv = None                       # the usual case: distinct genes in ascending column order
         ctx.set_expression(X, cols.astype(np.int32))
         if n_permutations > 0:
             ctx.generate_permutations(words, n_cells, n_permutations)  # continues the one stream
-        r = ctx.local_moran(n_cells, n_permutations)
-        z_values[:, b0:b1] = r["z"][:, inv]
-        lag_values[:, b0:b1] = r["lag"][:, inv]
-        local_I[:, b0:b1] = r["I"][:, inv]
-        zero_var_mask[b0:b1] = r["zero_var"][inv]
+        r = ctx.local_moran(n_cells, n_permutations, fetch_counts=False)
+        zero = r["zero_var"]
+        # per-cell p, adjusted p and quadrants on the device: lookup tables per (gene, permutation count) built here
+        # with the reference's expressions (AC:894-896, 912-920); zero-variance genes get p = p_adj = 1, quadrant 0
         if n_permutations > 0:
-            counts[:, b0:b1] = r["count"][:, inv]
-            p_values[:, b0:b1] = ((r["count"][:, inv] + 1) / (n_permutations + 1)).astype(np.float32)
+            hist = ctx.local_moran_hist(n_permutations)
+            hist[zero] = 0
+            hist[zero, n_permutations] = n_cells
+            p_tab = np.tile(levels, (cols.size, 1))
+            p_tab[zero] = 1.0
+            padj_tab = _padj_tables(hist, n_cells, n_permutations, fdr_correction)
+            padj_tab[zero] = 1.0
+            pb, ab, qb = ctx.local_moran_classify(n_cells, p_tab, padj_tab, zero, alpha)
+            p_values = put(p_values, pb, b0, b1, inv)
+            p_adj = put(p_adj, ab, b0, b1, inv)
+        else:
+            _, _, qb = ctx.local_moran_classify(n_cells, None, None, zero, alpha)
+        quadrants = put(quadrants, qb, b0, b1, inv)
+        for name in ("z", "lag", "I"):
+            if zero.any():
+                r[name][:, zero] = 0.0
+        z_values = put(z_values, r["z"], b0, b1, inv)
+        lag_values = put(lag_values, r["lag"], b0, b1, inv)
+        local_I = put(local_I, r["I"], b0, b1, inv)
+        zero_var_mask[b0:b1] = zero if inv is None else zero[inv]
 
     zero_variance_genes = [gene_names[i] for i in np.where(zero_var_mask)[0]]
     if zero_var_mask.any():
         logger.warning(f"{int(zero_var_mask.sum())} genes have zero variance and will be skipped: "
                        f"{zero_variance_genes[:5]}")
-        local_I[:, zero_var_mask] = 0.0
-        z_values[:, zero_var_mask] = 0.0
-        lag_values[:, zero_var_mask] = 0.0
-        p_values[:, zero_var_mask] = 1.0
-        counts[:, zero_var_mask] = n_permutations
-
     if n_permutations > 0:
-        logger.debug(f"Applying {fdr_correction} correction")
-        p_adj = np.ones_like(p_values)
-        for gene_idx in range(n_genes):
-            if fdr_correction == "fdr_bh":
-                p_adj[:, gene_idx] = _bh_from_counts(counts[:, gene_idx], n_permutations)
-            else:
-                p_adj[:, gene_idx] = _apply_fdr_correction(p_values[:, gene_idx], fdr_correction)
-        logger.debug("Classifying LISA quadrants (with significance filtering)")
-        quadrants = _classify_quadrants(z_values, lag_values, p_adj, alpha)
+        logger.debug(f"Applied {fdr_correction} correction; LISA quadrants with significance filtering")
     else:
         logger.warning("n_permutations=0: Quadrants classified by z/lag signs only, "
                        "without significance filtering. Consider n_permutations>=99 for p-values.")
+        p_values = np.ones((n_cells, n_genes), dtype=np.float32)
         p_adj = p_values
-        quadrants = _classify_quadrants(z_values, lag_values, p_values=None, alpha=alpha)
 
     adata.obsm[f"{key_added}_I"] = local_I
     adata.obsm[f"{key_added}_z"] = z_values

@@ -82,3 +82,23 @@ def test_quadrant_rules():
     q = _classify_quadrants(z, lag, np.array([0.01, 0.05, 0.2, 0.049, 0.0, 0.0]), alpha=0.05)
     assert [QUADRANT_LABELS[v] for v in q] == ["HH", "NS", "NS", "LH", "NS", "NS"]
     assert q.dtype == np.int8
+
+
+def test_padj_tables_match_per_gene_corrections():
+    """The per-(gene, count level) lookup tables handed to the device finalisation of local_morans_i give exactly
+    what the reference's per-gene FDR functions give cell by cell (BH via the count-level form, Bonferroni, none)."""
+    from spatialcore_amd.spatial.autocorrelation import (_apply_fdr_correction, _bh_from_counts, _padj_tables)
+
+    rng = np.random.default_rng(5)
+    n, P, G = 5000, 19, 6
+    counts = rng.integers(0, P + 1, (n, G))
+    counts[:, 2] = P                       # a degenerate gene: every cell at the top level
+    counts[:, 3] = rng.integers(0, 3, n)   # only a few levels populated
+    hist = np.stack([np.bincount(counts[:, g], minlength=P + 1) for g in range(G)])
+    p = ((counts + 1) / (P + 1)).astype(np.float32)
+    for method in ("fdr_bh", "bonferroni", "none"):
+        tab = _padj_tables(hist, n, P, method)
+        assert tab.dtype == np.float32 and tab.shape == (G, P + 1)
+        for g in range(G):
+            want = _bh_from_counts(counts[:, g], P) if method == "fdr_bh" else _apply_fdr_correction(p[:, g], method)
+            np.testing.assert_array_equal(tab[g][counts[:, g]], want, err_msg=f"{method} gene {g}")

@@ -161,6 +161,14 @@ def test_local_morans_i_vs_oracle_larger(oracle, dtype):
     r = oracle.local_morans_i(coords, X, np.arange(7), 6, 29, 3, fdr="fdr_bh", alpha=0.4, batch_size=4)
     for f in ("z", "lag", "I", "p", "p_adj", "quadrant"):
         np.testing.assert_array_equal(ad.obsm[f"local_morans_{f}"], r[f], err_msg=f)
+    # a gene list that is neither sorted nor free of repeats, every correction method, and no permutations at all
+    for fdr, P in (("bonferroni", 19), ("none", 19), ("fdr_bh", 0)):
+        genes = ["g3", "g1", "g3", "g0", "g6"]
+        ad2 = make_adata(coords, X)
+        local_morans_i(ad2, genes=genes, n_neighbors=6, n_permutations=P, seed=4, batch_size=3, fdr_correction=fdr, alpha=0.3)
+        r2 = oracle.local_morans_i(coords, X, np.array([3, 1, 3, 0, 6]), 6, P, 4, fdr=fdr, alpha=0.3, batch_size=3)
+        for f in ("z", "lag", "I", "p", "p_adj", "quadrant"):
+            np.testing.assert_array_equal(ad2.obsm[f"local_morans_{f}"], r2[f], err_msg=f"{fdr} P={P} {f}")
     with pytest.raises(ValueError, match="Invalid fdr_correction"):
         local_morans_i(ad, fdr_correction="holm")
 
