@@ -80,6 +80,7 @@ int sc_timer_collect(sc_ctx *c)
     if (c->stream4) SC_HIP(hipStreamSynchronize(c->stream4));
     for (hipStream_t sp : c->stream_pg)
         if (sp) SC_HIP(hipStreamSynchronize(sp));
+    if (c->stream_px) SC_HIP(hipStreamSynchronize(c->stream_px));
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         KTimer &t = c->timers[k];
         for (auto &ev : t.pending) {
@@ -172,6 +173,7 @@ int sc_ctx_destroy(sc_ctx *c)
     for (hipStream_t sp : c->stream_pg)
         if (sp) (void)hipStreamDestroy(sp);
     if (c->stream_score) (void)hipStreamDestroy(c->stream_score);
+    if (c->stream_px) (void)hipStreamDestroy(c->stream_px);
     for (hipEvent_t e : c->pg_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);

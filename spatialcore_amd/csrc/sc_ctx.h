@@ -64,7 +64,8 @@ struct sc_ctx {
     hipStream_t stream_score = nullptr;  // scoring stream of the fused pipeline: every CU but the few left to the generator
     bool stream_score_failed = false;    // the runtime refused CU masks: scoring stays on the main stream
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
-    hipEvent_t pg_ev[33] = {};        // rings of events between the preparation and the chain launches + start marker
+    hipStream_t stream_px = nullptr;     // ... and verifies + expands a finished chunk here, beside the next chunk's chain
+    hipEvent_t pg_ev[34] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
     int pg_ahead = 1;                 // launch units the preparation runs ahead of the chain (callers that share the chip raise it)
     int64_t pg_jobs_parallel = 0, pg_jobs_sequential = 0, pg_fallbacks = 0;  // generator jobs by scan form
@@ -155,7 +156,7 @@ struct PermJob {
 #define SC_PERMGEN_RETRY 1000  // internal: the block-parallel scan failed its verification, rerun sequentially
 bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);
-int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s);
+int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipStream_t post, hipEvent_t done);
 int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s);
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);
 int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm);

@@ -857,6 +857,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
             SC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         }
     }
+    if (!c->stream_px) SC_HIP(hipStreamCreateWithFlags(&c->stream_px, hipStreamNonBlocking));
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     if (!c->stream4) SC_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
     // allocations first (hipMalloc synchronises the device), then the two streams run freely
@@ -884,10 +885,9 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     auto generate = [&](int64_t k) -> int {
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
         hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
-        SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2));
         SC_HIP(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
         SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
-        SC_HIP(hipEventRecord(scanned, c->stream2));
+        SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
         SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
         SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
         // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
@@ -914,6 +914,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+    if (c->stream_px) (void)hipStreamSynchronize(c->stream_px);
     for (hipStream_t sp : c->stream_pg)
         if (sp) (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(c->stream);

@@ -799,10 +799,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         st[4] += n_easy;  // wavefront 0 counted them
         st[5] += n_hard;
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
-        unsigned long long f = st[2];
+        unsigned long long f = 0;  // (k_block_exact of the previous chunk may be raising its own flag right now)
         if (failed) f |= 1ull;
         if (S < S_need && S < total_steps) f |= 2ull;  // the blocks granted to this chunk did not complete it
-        st[2] = f;
+        if (f) atomicOr(st + 2, f);
     }
 }
 
@@ -1021,9 +1021,9 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
                 SC_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
             }
         }
-        for (hipEvent_t &e : c->pg_ev)
-            if (!e) SC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    for (hipEvent_t &e : c->pg_ev)
+        if (!e) SC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // pg_out: [0..3] scan state, [4] prepared blocks used, [5] blocks computed by the chain, then one
     // {first block, end block} pair per chunk for k_expand
     const int64_t chunks = ceil_div64(n_perm, PERM_CHUNK) + 2;  // the fused pipeline splits its first chunk
@@ -1057,7 +1057,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
 
 // Advance the rejection scan until permutations [0, p1) are complete, then expand the accept masks
 // of the blocks it processed into J (both on stream s; the expansion uses the whole chip).
-int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
+int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipStream_t post, hipEvent_t done)
 {
     if (job->trivial) return SC_OK;
     const uint64_t n_blocks = job->hi / SCAN_BLOCK;
@@ -1115,6 +1115,13 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
                            c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
     }
     SC_HIP(hipMemcpyAsync(range + 1, st + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    // Verification and expansion of the chunk use the whole chip for ~2.5 ms: on `post` (if given) they do not hold
+    // up the chain of the next chunk on s.  They only read what this chunk's chain left and write J.
+    hipStream_t sp = post ? post : s;
+    if (sp != s) {
+        SC_HIP(hipEventRecord(c->pg_ev[33], s));
+        SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[33], 0));
+    }
     // blocks this launch can have covered: the chunk's expected draws + 1 % + 2 blocks
     const double chunk_perms = (double)(p1 - job->p_done);
     uint64_t max_blocks = (uint64_t)(chunk_perms * job->draws_per_perm * 1.01 / SCAN_BLOCK) + 3;
@@ -1122,15 +1129,16 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s)
         max_blocks = phi_end - phi_first;
         if (max_blocks == 0) max_blocks = 1;
         // the prepared blocks again, from their exact entry states, on the whole chip + verification of the chain
-        KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
-        hipLaunchKernelGGL(k_block_exact, dim3((unsigned)max_blocks), dim3(SCAN_THREADS), 0, s,
+        KernelTimerScope ts(c, SC_K_PERM_SCAN, sp);
+        hipLaunchKernelGGL(k_block_exact, dim3((unsigned)max_blocks), dim3(SCAN_THREADS), 0, sp,
                            c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, range, c->pg_hard.as<uint8_t>(),
                            c->pg_bits.as<bits_t>(), c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
     }
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)(max_blocks * SCAN_THREADS / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)(max_blocks * SCAN_THREADS / 256)), dim3(256), 0, sp,
                        c->pg_raw.as<uint32_t>(), c->pg_bits.as<bits_t>(), c->pg_enter.as<uint32_t>(),
                        c->pg_sblk.as<unsigned long long>(), range, (uint32_t)job->n, job->total_steps,
                        c->pg_J.as<int32_t>());
+    if (done) SC_HIP(hipEventRecord(done, sp));
     SC_HIP(hipGetLastError());
     job->p_done = p1;
     job->chunk_no += 1;
@@ -1192,7 +1200,7 @@ static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_
     SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream));
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) {
         const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
-        SC_TRY(permgen_scan_chunk(c, &job, p1, c->stream));
+        SC_TRY(permgen_scan_chunk(c, &job, p1, c->stream, nullptr, nullptr));
     }
     SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
