@@ -440,6 +440,10 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
                                   // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
 #define PHI_RING 2048             // table ring slots (> PHI_AHEAD_MAX + 2 units)
 #define PHI_STREAMS 4             // preparation streams (units rotate over them)
+#ifndef PHI_GROUP
+#define PHI_GROUP 1               // launch units chained by one k_chain launch (measured in the pipeline: 2 -> -1.3 %,
+                                  // 4 -> -18 %: the launch has to wait for the preparation of all its units)
+#endif
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
 
 struct PhiDesc {
@@ -677,7 +681,7 @@ __device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_
 // then LDS).  Leaves sblk[b] for every block, hardmask[b], and the accept masks / entering counts of the blocks it
 // computed itself.  fault != 0 (testing): corrupt one lookup.
 __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restrict__ raw, uint64_t n_blocks,
-                                                        uint32_t n, uint64_t total_steps, uint64_t b0, uint64_t b1,
+                                                        uint32_t n, uint64_t total_steps, uint64_t B0, uint64_t B1,
                                                         uint64_t S_need, const PhiDesc *__restrict__ desc,
                                                         const unsigned long long *__restrict__ tbits,
                                                         uint8_t *__restrict__ hardmask, int fault,
@@ -694,8 +698,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
     const uint32_t M = n - 1, top_mask = mask_of(M);
     uint64_t S = st[0];
-    if (S >= total_steps || st[1] != b0 || b1 > n_blocks || b1 - b0 > PHI_UNIT) return;  // job complete (uniform)
+    if (S >= total_steps || st[1] != B0 || B1 > n_blocks) return;  // job complete (uniform)
+    uint32_t parity = 0;
+    int failed = 0;
+    uint64_t endpos = 0;
+    uint32_t n_easy = 0, n_hard = 0;
+    uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
+    uint64_t b_next = B0;
+    // one launch chains several launch units (each prepared by its own launches; the host waited for all of them)
+    for (uint64_t b0 = B0; b0 < B1 && !failed && S < total_steps; b0 += PHI_UNIT) {
+    const uint64_t b1 = b0 + PHI_UNIT < B1 ? b0 + PHI_UNIT : B1;
     const uint32_t nb = (uint32_t)(b1 - b0);
+    __syncthreads();  // the previous unit's readers of dsc / nxt / tl are done
     if (tau < nb) dsc[tau] = desc[(b0 + tau) % PHI_RING];
     __syncthreads();
     if (tau <= nb) {
@@ -722,11 +736,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     uint32_t staged = h - rel < PHI_STAGE ? h - rel : PHI_STAGE;
     PHI_STAGE_LOAD(rel, staged)
     if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
-    uint32_t parity = 0;
-    int failed = 0;
-    uint64_t endpos = 0;
-    uint32_t n_easy = 0, n_hard = 0;
-    uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
     for (;;) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -790,10 +799,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         h = hN;
         if (S >= total_steps) break;
     }
+    b_next = b0 + rel;
+    }  // units
 #undef PHI_STAGE_LOAD
     if (endpos) st[3] = endpos;
     if (tau == 0) {
-        const uint64_t b = b0 + rel;
+        const uint64_t b = b_next;
         st[0] = S;
         st[1] = b;
         st[4] += n_easy;  // wavefront 0 counted them
@@ -1077,35 +1088,43 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
         phi_end = B_end;
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
         while (job->B_done < B_end) {
-            const uint64_t b0 = job->B_done;
-            const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
-            const int64_t u = job->unit_no;
-            hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
-            hipEvent_t ev_prep = c->pg_ev[(size_t)(u % 16)], ev_chain = c->pg_ev[(size_t)(16 + u % 16)];
-            // The guess of unit u uses the exact state at the start of unit u - ahead, which chain(u - ahead - 1)
-            // leaves; that launch also is the last reader of the ring slots unit u overwrites.
-            const int64_t dep = u - job->ahead - 1;
-            const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
-            if (dep >= 0) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[(size_t)(16 + dep % 16)], 0));
-            else SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
-            hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
-                               c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0, b1,
-                               ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
-                               c->pg_events.as<uint16_t>());
-            hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
-                               c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
-                               c->pg_tbits.as<unsigned long long>());
-            SC_HIP(hipEventRecord(ev_prep, sp));
-            SC_HIP(hipStreamWaitEvent(s, ev_prep, 0));
+            // a group of launch units: each prepared by its own launches, chained by ONE launch
+            const uint64_t g0 = job->B_done;
+            const int64_t u_first = job->unit_no;
+            int in_group = 0;
+            while (job->B_done < B_end && in_group < PHI_GROUP) {
+                const uint64_t b0 = job->B_done;
+                const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
+                const int64_t u = job->unit_no;
+                hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
+                hipEvent_t ev_prep = c->pg_ev[(size_t)(u % 16)];
+                // The guess of unit u uses the exact state at the start of unit u - ahead, which the chain launch of
+                // unit u - ahead - 1 leaves; that launch also is the last reader of the ring slots unit u overwrites.
+                const int64_t dep = u - job->ahead - 1;
+                const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
+                if (dep >= 0) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[(size_t)(16 + dep % 16)], 0));
+                else SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
+                hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
+                                   c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0,
+                                   b1, ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
+                                   c->pg_events.as<uint16_t>());
+                hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
+                                   c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
+                                   c->pg_tbits.as<unsigned long long>());
+                SC_HIP(hipEventRecord(ev_prep, sp));
+                SC_HIP(hipStreamWaitEvent(s, ev_prep, 0));
+                job->unit_start[(size_t)(u % 8)] = b0;
+                job->B_done = b1;
+                job->unit_no = u + 1;
+                ++in_group;
+            }
+            const uint64_t g1 = job->B_done;
             hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
-                               (uint32_t)job->n, job->total_steps, b0, b1, b1 == B_end ? target : 0ull,
+                               (uint32_t)job->n, job->total_steps, g0, g1, g1 == B_end ? target : 0ull,
                                c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(),
-                               c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
+                               c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
                                c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
-            SC_HIP(hipEventRecord(ev_chain, s));
-            job->unit_start[(size_t)(u % 8)] = b0;
-            job->B_done = b1;
-            job->unit_no = u + 1;
+            for (int64_t u = u_first; u < job->unit_no; ++u) SC_HIP(hipEventRecord(c->pg_ev[(size_t)(16 + u % 16)], s));
         }
         SC_HIP(hipGetLastError());
     } else {
