@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_WORDS (PHI_W / 64)
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
 #ifndef PHI_UNIT
-#define PHI_UNIT 160              // blocks per launch unit
+#define PHI_UNIT 224              // blocks per launch unit (the chain pays ~0.17 ms between launches: 80 -> 842,
+                                  // 112 -> 900, 160 -> 1017, 224 -> 1024, 320 -> 1020-1033 genes/s in the pipeline)
 #endif
 #define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
                                   // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
