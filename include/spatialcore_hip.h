@@ -76,7 +76,7 @@ int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
 int sc_ctx_set_permgen_mode(sc_ctx *ctx, int mode);
 /* Completed generator jobs by scan form, how often the block-parallel form failed its verification and the
  * job was rerun sequentially (0 unless mode 2 injected a fault), and for the block-parallel jobs (failed ones
- * included) the 32768-draw blocks resolved by a prepared table lookup / computed by the chain workgroup itself. */
+ * included) the 16384-draw blocks resolved by a prepared table lookup / computed by the chain workgroup itself. */
 int sc_ctx_permgen_stats(sc_ctx *ctx, int64_t *jobs_parallel, int64_t *jobs_sequential, int64_t *fallbacks,
                          int64_t *blocks_prepared, int64_t *blocks_chain);
 

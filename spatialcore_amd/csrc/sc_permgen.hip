@@ -10,8 +10,8 @@
 //  A0  raw stream   PCG64 is an LCG, so output m is a pure function of m (jump-ahead in O(log m)
 //                   128-bit multiplies).  The whole raw 32-bit stream is produced in one massively
 //                   parallel kernel (each lane strides by 64 outputs with the constant A^64, C_64).
-//  A1  rejection    ONE 1024-thread workgroup walks the raw stream in blocks of 32768 draws.  Each
-//                   thread simulates its 32 consecutive draws sequentially (exact semantics) from a
+//  A1  rejection    A 1024-thread workgroup resolves the raw stream in blocks of 16384 draws.  Each
+//                   thread simulates its 16 consecutive draws sequentially (exact semantics) from a
 //                   guessed number of accepts in front of it; a workgroup prefix sum of the accept
 //                   counts gives new entering counts; this repeats until no entering count changes.
 //                   A thread whose entering count is right produces the right count, so the correct
@@ -84,7 +84,8 @@ __host__ __device__ static inline uint64_t xsl_rr(u128 s)
 #define SCAN_THREADS 1024
 #endif
 #ifndef SCAN_D
-#define SCAN_D 32
+#define SCAN_D 16  // draws per thread and round (r01 sweep at 1M cells, sequential / block-parallel scan of 300
+                   // permutations: 8 -> 145 / 83 ms, 12 -> 119 / 72, 16 -> 107 / 58, 20 -> 103 / 59, 24 -> 114 / 63, 32 -> 154 / 84)
 #endif
 #define SCAN_BLOCK (SCAN_THREADS * SCAN_D)
 #define SCAN_GROUPS (SCAN_D / 4)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_raw_stream(uint64_t st_hi, uint64_t st_
     const uint32_t tau = (uint32_t)(t % SCAN_THREADS), g = (uint32_t)((t / SCAN_THREADS) % SCAN_GROUPS);
     uint64_t b = (t / (SCAN_THREADS * SCAN_GROUPS)) * RAW_BLOCKS;
     if (b >= n_blocks) return;
-    // first draw of the group: r = b*32768 + 32*tau + 4*g  ->  64-bit output m = r / 2
+    // first draw of the group: r = b*SCAN_BLOCK + SCAN_D*tau + 4*g  ->  64-bit output m = r / 2
     const uint64_t m = b * (SCAN_BLOCK / 2) + (uint64_t)(SCAN_D / 2) * tau + 2ull * g;
     const Affine j = lcg_pow(inc, m + 1);  // output m is made from the state after m + 1 steps
     u128 s = j.mult * state0 + j.plus;
@@ -433,8 +434,9 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_WORDS (PHI_W / 64)
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
 #ifndef PHI_UNIT
-#define PHI_UNIT 224              // blocks per launch unit (the chain pays ~0.17 ms between launches: 80 -> 842,
-                                  // 112 -> 900, 160 -> 1017, 224 -> 1024, 320 -> 1020-1033 genes/s in the pipeline)
+#define PHI_UNIT 512              // blocks per launch unit (the chain pays ~0.17 ms between launches; with 32-draw
+                                  // threads: 80 -> 842, 112 -> 900, 160 -> 1017, 224 -> 1024, 320 -> 1020-1033 genes/s in
+                                  // the pipeline; with 16-draw threads: 384 -> 1068, 448 -> 1067, 512 -> 1071)
 #endif
 #define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
                                   // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
@@ -446,6 +448,8 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
                                   // 4 -> -18 %: the launch has to wait for the preparation of all its units)
 #endif
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
+
+static_assert((PHI_AHEAD_MAX + 1) * PHI_UNIT <= PHI_RING, "a unit's ring slots are reused only after the chain consumed them");
 
 struct PhiDesc {
     unsigned long long G;  // guessed entry state of the block
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
             if (d >= 0) { np += ((uint32_t)d < w_pos) ? 1u : 0u; --thr; }
             else nn += ((uint32_t)(-d - 1) < w_neg) ? 1u : 0u;
         }
-        const uint32_t pk = np | (nn << 16);  // both totals <= 32768: no carry between the fields
+        const uint32_t pk = np | (nn << 16);  // both totals <= SCAN_BLOCK <= 65535: no carry between the fields
         const uint32_t incl = wave_inclusive_scan(pk);
         if (lane == 63) wpk[wave] = incl;
         __syncthreads();
@@ -659,7 +663,9 @@ __global__ __launch_bounds__(128) void k_phi_tbuild(uint64_t b0, uint64_t b1, co
                tbits + (slot * 2 + side) * PHI_WORDS);
 }
 
-#define PHI_STAGE 24          // prepared blocks of a run whose tables are staged in LDS
+#ifndef PHI_STAGE
+#define PHI_STAGE 16          // prepared blocks of a run whose tables are staged in LDS
+#endif
 #define PHI_STAGE_WORDS 128   // ... their first 8192 bits per side (entry gaps beyond that read global memory)
 
 // exit gap from a staged table (wave 0 only, all lanes): lane l holds bits [128 l, 128 l + 128)
