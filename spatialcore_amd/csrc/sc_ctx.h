@@ -11,7 +11,9 @@
 #include "../../include/spatialcore_hip.h"
 
 #define SC_TILE 16  // genes per tile: one 128-byte fp64 row per cell and tile
+#ifndef PERM_CHUNK
 #define PERM_CHUNK 128  // permutations per pipeline stage (generator scan -> swaps -> scoring)
+#endif
 
 void sc_set_error(const char *fmt, ...);
 

@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_W 16384               // window bits per side
 #define PHI_WORDS (PHI_W / 64)
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
+#ifndef PHI_WINDOW
+#define PHI_WINDOW 2.25           // window half-width in units of sqrt(draws since the reference state) (= 4.5 sigma)
+#endif
 #ifndef PHI_UNIT
 #define PHI_UNIT 512              // blocks per launch unit (the chain pays ~0.17 ms between launches; with 32-draw
                                   // threads: 80 -> 842, 112 -> 900, 160 -> 1017, 224 -> 1024, 320 -> 1020-1033 genes/s in
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
         shG = phi_expect(sblk[ref_block], dq, M, dpp, total_steps);
         // ~4.5 sigma of the random walk since the reference state (sigma = 0.49 sqrt(draws), measured); an entry
         // state outside the window only costs the chain one computed block
-        const double wd = 2.25 * sqrt(dq) + 64.0;
+        const double wd = PHI_WINDOW * sqrt(dq) + 64.0;
         shw = wd < (double)(PHI_W - 1) ? (uint32_t)wd : (uint32_t)(PHI_W - 1);
         shi = M - (uint32_t)(shG % M);
     }
