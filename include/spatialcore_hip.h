@@ -150,7 +150,8 @@ int sc_moran(sc_ctx *ctx, int64_t n_perm, double *I_out, double *sims_out, int64
  * on a few CUs the scoring stream leaves free) while the rest of the chip applies the swaps and scores the
  * previous chunk of permutations.
  * state6 is advanced exactly as n_perm calls of rng.permutation(n_cells) would; the table stays
- * resident as the active permutation table. */
+ * resident as the active permutation table (for a float32 matrix the pipeline only builds its inverse, the same
+ * Fisher-Yates transpositions in ascending order; the rows themselves are materialised when a later call needs them). */
 int sc_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
                     int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out);
 

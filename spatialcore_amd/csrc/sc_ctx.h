@@ -114,6 +114,7 @@ struct sc_ctx {
     DBuf perm;
     DBuf perm_flag;
     DBuf inv;                      // inverse permutations, same layout as perm (rows valid on demand)
+    bool perm_forward_valid = true; // c->perm holds the active table (false: only its inverse, c->inv, was generated)
     bool perm_bijective = false;   // the active table is known to hold true permutations
     bool perm_checked = false;     // ... or was checked and is not
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
@@ -159,7 +160,9 @@ struct PermJob {
 bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);
 int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipStream_t post, hipEvent_t done);
-int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s);
+int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse);
+bool permgen_can_swap_inverse(int64_t n);
+int sc_perm_forward_ensure(sc_ctx *c);  // materialise c->perm from c->inv after a pipeline that only made the inverse
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);
 int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm);
 

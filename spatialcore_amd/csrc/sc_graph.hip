@@ -936,6 +936,7 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
 {
     SC_REQUIRE(c && labels && counts_out, SC_ERR_INVALID, "sc_enrichment_counts: null pointer");
     SC_HIP(hipSetDevice(c->device));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     SC_REQUIRE(c->g_n > 0 && n == c->g_n, SC_ERR_STATE, "sc_enrichment_counts: graph missing or size mismatch");
     SC_REQUIRE(n_types >= 1 && n_types <= 96, SC_ERR_INVALID, "sc_enrichment_counts: n_types must be 1..96");
     SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_enrichment_counts: negative size");

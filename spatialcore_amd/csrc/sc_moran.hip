@@ -696,6 +696,21 @@ static int invert_rows(sc_ctx *c, int64_t p0, int64_t p1, hipStream_t s)
     return SC_OK;
 }
 
+// After a seeded pipeline that only generated the inverse table: materialise the permutation table itself (the
+// inverse of the inverse) for callers that use the resident table afterwards.
+int sc_perm_forward_ensure(sc_ctx *c)
+{
+    if (c->perm_forward_valid || c->p_count <= 0) return SC_OK;
+    const int rows = (int)c->p_count;
+    const int groups = (rows + 7) / 8;
+    hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(groups * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0, c->stream,
+                       c->inv.as<int32_t>(), c->perm.as<int32_t>(), c->p_n, c->p_stride, rows);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(c->stream));
+    c->perm_forward_valid = true;
+    return SC_OK;
+}
+
 // Decide whether the half-traffic kernel may be used for the active table; a table uploaded by the
 // caller is only trusted after checking that every row is a bijection (inverse of the inverse).
 // narrowest exact source the scoring may gather: 32 (float32 raw values), 64 (the fp64 kernel)
@@ -811,6 +826,7 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
                         double *sim_sum_out, double *sim_sumsq_out)
 {
     SC_TRY(moran_check(c, n_perm, I_out));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     if (n_perm > 0) {
         SC_REQUIRE(c->p_count >= n_perm, SC_ERR_STATE, "sc_moran: permutation table holds %lld rows, need %lld",
                    (long long)c->p_count, (long long)n_perm);
@@ -882,6 +898,8 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     // stream2: scan(0) scan(1) ...   stream3/4: swaps(k) + inverse(k) after scan(k)   stream: score(k) after swaps(k)
     std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
     PermJob job;
+    // a float32 matrix is its own exact float32 copy: the scoring will gather through the inverse table only
+    const bool inverse_only = c->e_dtype == SC_F32 && c->source_bits_min <= 32 && permgen_can_swap_inverse(n);
     auto generate = [&](int64_t k) -> int {
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
         hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
@@ -889,9 +907,15 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
         SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
         SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
-        SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
-        // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
-        SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
+        if (inverse_only) {
+            // the float32-source kernel only gathers through the inverse table, and the inverse of a Fisher-Yates
+            // result is the same transpositions in ascending order: no permutation table, no scatter pass
+            SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, true));
+        } else {
+            SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, false));
+            // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
+            SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
+        }
         SC_HIP(hipEventRecord(swapped, sw));
         return SC_OK;
     };
@@ -903,11 +927,21 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
     c->perm_bijective = true;  // device-generated rows are permutations by construction
     const int bits = moran_source_bits(c);
+    // (a float32 matrix with NaNs fails the exactness test of its float32 copy: the fp64 kernel then needs the
+    // permutation rows themselves, made below from the inverse rows chunk by chunk)
+    const bool need_forward = inverse_only && bits != 32;
+    c->perm_forward_valid = !inverse_only || need_forward;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
         if (k + 1 < chunks) rc = generate(k + 1);
         if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("sc_moran_seeded: event plumbing failed");
             rc = SC_ERR_HIP;
+        }
+        if (rc == SC_OK && need_forward) {
+            const int rows = (int)(bounds[(size_t)k + 1] - bounds[(size_t)k]);
+            hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((rows + 7) / 8) * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0,
+                               c->stream, c->inv.as<int32_t>() + bounds[(size_t)k] * c->p_stride,
+                               c->perm.as<int32_t>() + bounds[(size_t)k] * c->p_stride, c->e_n, c->p_stride, rows);
         }
         if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1], bits, false);
     }
@@ -1063,6 +1097,7 @@ extern "C" int sc_lee(sc_ctx *c, const int32_t *pair_x, const int32_t *pair_y, c
     SC_REQUIRE(c && pair_x && pair_y && L_out, SC_ERR_INVALID, "sc_lee: null pointer");
     SC_REQUIRE(n_pairs >= 0 && n_perm >= 0, SC_ERR_INVALID, "sc_lee: negative size");
     SC_HIP(hipSetDevice(c->device));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_lee: no expression loaded");
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_lee: graph missing or size mismatch");
     SC_REQUIRE(n_perm == 0 || perm_offset, SC_ERR_INVALID, "sc_lee: perm_offset required when n_perm > 0");
@@ -1462,6 +1497,7 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
     SC_REQUIRE(c && z_out && lag_out && I_out, SC_ERR_INVALID, "sc_local_moran: null pointer");
     SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_local_moran: negative size");
     SC_HIP(hipSetDevice(c->device));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran: no expression loaded");
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran: graph missing or size mismatch");
     c->lm_valid = false;
@@ -1715,6 +1751,7 @@ extern "C" int sc_lee_local(sc_ctx *c, int32_t gene_x, int32_t gene_y, int64_t n
 {
     SC_REQUIRE(c && zx_out && lag_out && L_local_out, SC_ERR_INVALID, "sc_lee_local: null pointer");
     SC_HIP(hipSetDevice(c->device));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_lee_local: no expression loaded");
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_lee_local: graph missing or size mismatch");
     SC_REQUIRE(gene_x >= 0 && gene_x < c->e_genes && gene_y >= 0 && gene_y < c->e_genes, SC_ERR_INVALID,

@@ -132,6 +132,7 @@ int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
     c->p_stride = stride;
     c->perm_bijective = false;
     c->perm_checked = false;
+    c->perm_forward_valid = true;
     return SC_OK;
 }
 

@@ -920,6 +920,13 @@ __global__ __launch_bounds__(64) void k_apply_swaps(const int32_t *__restrict__ 
 #endif
 #define SW_HASH 2048
 
+// ASC = false: the shuffle itself (steps i = n-1 .. 1), the table numpy returns.
+// ASC = true:  the same transpositions applied in the opposite order (i = 1 .. n-1) to the identity.  With position
+//              swaps s_1 .. s_m applied in order the array is s_1 o s_2 o .. o s_m (position -> value), so the opposite
+//              order yields its inverse: the INVERSE permutation table comes out of the same kernel, no scatter pass.
+//              Two steps of a round then collide when a later step's target is an earlier step's own slot
+//              (j_l == i_m, again index arithmetic) or two steps share a target.
+template <bool ASC>
 __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
                                                          int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
 {
@@ -936,11 +943,11 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int64_t i_top = (int64_t)n - 1;
+    int64_t i_cur = ASC ? 1 : (int64_t)n - 1;  // first step of the round
     uint32_t round = 0;
-    while (i_top >= 1) {
-        const int64_t i = i_top - l;
-        const bool valid = i >= 1;
+    while (ASC ? i_cur <= (int64_t)n - 1 : i_cur >= 1) {
+        const int64_t i = ASC ? i_cur + l : i_cur - l;
+        const bool valid = ASC ? i <= (int64_t)n - 1 : i >= 1;
         int32_t j = valid ? Jp[(int64_t)M - i] : -1;
         if (valid && (uint32_t)j > (uint32_t)i) j = (int32_t)i;  // never index outside [0, i], whatever J holds
         int32_t a_i = 0, a_j = 0;
@@ -954,8 +961,13 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
         uint32_t *fc = &first_conf[round & 1];
         uint32_t h = 0;
         if (valid) {
-            const int64_t t = i_top - j;  // the step whose own slot is j (t >= l; t == l is a self swap)
-            if (t < SW_T && t != (int64_t)l) atomicMin(fc, (uint32_t)t);
+            if (ASC) {
+                const int64_t t = j - i_cur;  // the step whose own slot is my target (t <= l; t == l is a self swap)
+                if (t >= 0 && t < (int64_t)l) atomicMin(fc, l);
+            } else {
+                const int64_t t = i_cur - j;  // the step whose own slot is j (t >= l; t == l is a self swap)
+                if (t < SW_T && t != (int64_t)l) atomicMin(fc, (uint32_t)t);
+            }
             h = ((uint32_t)j * 2654435761u) >> 21;
             for (;;) {
                 const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, (uint32_t)j);
@@ -969,7 +981,8 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
         if (l == 0) first_conf[(round + 1) & 1] = SW_T;  // next round's cell (nobody touches it this round)
         __syncthreads();
         uint32_t count = *fc;
-        const int64_t nvalid = i_top < SW_T ? i_top : SW_T;
+        const int64_t left = ASC ? (int64_t)n - i_cur : i_cur;  // steps not yet applied
+        const int64_t nvalid = left < SW_T ? left : SW_T;
         if ((int64_t)count > nvalid) count = (uint32_t)nvalid;
         if (l < count) {
             A[i] = a_j;
@@ -977,7 +990,7 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        i_top -= count;
+        i_cur += ASC ? (int64_t)count : -(int64_t)count;
         ++round;
     }
 }
@@ -1174,12 +1187,25 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
     return SC_OK;
 }
 
-int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s)
+bool permgen_can_swap_inverse(int64_t n) { return n >= SWAPS_WG_MIN_N; }
+
+// inverse = false: rows [p0, p1) of the permutation table (c->perm); true: of its inverse (c->inv), by the same
+// transpositions in ascending order (workgroup kernel only: see permgen_can_swap_inverse)
+int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse)
 {
-    if (job->trivial || p1 <= p0) return SC_OK;
+    if (job->trivial || p1 <= p0) {
+        if (job->trivial && inverse && p1 > p0)
+            SC_HIP(hipMemsetAsync(c->inv.as<int32_t>() + p0 * c->p_stride, 0, sizeof(int32_t) * (size_t)(c->p_stride * (p1 - p0)), s));
+        return SC_OK;
+    }
+    SC_REQUIRE(!inverse || permgen_can_swap_inverse(job->n), SC_ERR_STATE, "permgen_swap_chunk: inverse tables need n >= %d",
+               SWAPS_WG_MIN_N);
     KernelTimerScope ts(c, SC_K_PERM_SWAP, s);
-    if (job->n >= SWAPS_WG_MIN_N)
-        hipLaunchKernelGGL(k_apply_swaps_wg, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+    if (inverse)
+        hipLaunchKernelGGL(k_apply_swaps_wg<true>, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+                           c->inv.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    else if (job->n >= SWAPS_WG_MIN_N)
+        hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
                            c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
     else
         hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)(p1 - p0)), dim3(64), 0, s, c->pg_J.as<int32_t>(),
@@ -1231,7 +1257,8 @@ static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_
         const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
         SC_TRY(permgen_scan_chunk(c, &job, p1, c->stream, nullptr, nullptr));
     }
-    SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream));
+    SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream, false));
+    c->perm_forward_valid = true;
     SC_HIP(hipStreamSynchronize(c->stream));
     for (hipStream_t sp : c->stream_pg)
         if (sp) SC_HIP(hipStreamSynchronize(sp));

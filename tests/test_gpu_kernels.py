@@ -256,6 +256,45 @@ def test_moran_seeded_pipeline_equals_two_step(ctx, oracle, n, G, P):
     assert_counts_match(one["count_ge"], tab["sims"], tab["I"])
 
 
+def test_moran_seeded_inverse_only_tables(ctx, oracle):
+    """n >= 65536 with a float32 matrix: the pipeline never builds the permutation table, only its inverse (the same
+    Fisher-Yates transpositions applied in ascending order).  Scores must equal the two-step path bit for bit, and
+    calls that use the resident table afterwards (sc_moran, a fetch through sc_lee) see the table numpy returns."""
+    from spatialcore_amd._lib import rng_state_words, perm_numpy_host
+
+    n, G, P = 70001, 6, 150
+    coords, X = synth(n, G, 2, dtype=np.float32, sparse_x=False)
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, np.arange(G))
+    w1 = rng_state_words(np.random.default_rng(11))
+    ctx.generate_permutations(w1, n, P)
+    two = ctx.moran(P)
+    w2 = rng_state_words(np.random.default_rng(11))
+    one = ctx.moran_seeded(w2, P)
+    assert ctx.moran_source_bits() == 32
+    np.testing.assert_array_equal(w1, w2)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    again = ctx.moran(P)                       # the resident table: forward rows are materialised on demand
+    np.testing.assert_array_equal(again["sims"], two["sims"])
+    # NaN in a float32 matrix: its float32 copy is "inexact", the fp64 kernel runs and needs the forward rows
+    Xn = X.copy(); Xn[5, 1] = np.nan
+    ctx.set_expression(Xn, np.arange(G))
+    w3 = rng_state_words(np.random.default_rng(11))
+    nan_run = ctx.moran_seeded(w3, P)
+    assert ctx.moran_source_bits() == 64 and np.isnan(nan_run["I"][1])
+    keep = [0, 2, 3, 4, 5]
+    np.testing.assert_allclose(nan_run["sims"][:, keep], two["sims"][:, keep], rtol=1e-9, atol=1e-13)
+    want = perm_numpy_host(rng_state_words(np.random.default_rng(11)), n, P)
+    ctx.set_expression(X, np.arange(G))
+    ctx.moran_seeded(rng_state_words(np.random.default_rng(11)), P)
+    lee = ctx.lee(np.array([0]), np.array([1]), np.array([0], dtype=np.int64), P, return_perms=True)
+    ctx.set_permutations(want)
+    lee2 = ctx.lee(np.array([0]), np.array([1]), np.array([0], dtype=np.int64), P, return_perms=True)
+    np.testing.assert_array_equal(lee["L_perm"], lee2["L_perm"])
+
+
 @pytest.mark.parametrize("G", [5, 32, 47, 70])
 def test_moran_source_widths_agree(ctx, oracle, G):
     """The permutation kernels gather the narrowest EXACT copy of the raw values: float32 (32 genes per row) when
