@@ -96,7 +96,7 @@ struct sc_ctx {
     bool gt_valid = false;
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
     bool s0_valid = false;
-    double s0 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // graph moments (valid with s0_valid)
 
     // ---- expression tiles ----
     int64_t e_n = 0, e_genes = 0, e_tiles = 0;

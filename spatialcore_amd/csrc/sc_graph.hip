@@ -634,6 +634,10 @@ __global__ __launch_bounds__(256) void k_moments(const long long *__restrict__ i
 static int graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
 {
     SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    if (c->s0_valid) {  // a function of the graph alone: computed once per graph (the Moran path asks twice)
+        *s0 = c->s0; *s1 = c->s1; *s2 = c->s2;
+        return SC_OK;
+    }
     SC_TRY(sc_graph_ensure_transpose(c));
     int64_t n = c->g_n;
     int blocks = (int)ceil_div64(n, MOM_ROWS_PER_BLOCK);
@@ -648,7 +652,7 @@ static int graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
     double a0 = 0, a1 = 0, a2 = 0;
     for (int b = 0; b < blocks; ++b) { a0 += h[3 * b]; a1 += h[3 * b + 1]; a2 += h[3 * b + 2]; }
     *s0 = a0; *s1 = a1 / 2.0; *s2 = a2;
-    c->s0 = a0;
+    c->s0 = a0; c->s1 = a1 / 2.0; c->s2 = a2;
     c->s0_valid = true;
     return SC_OK;
 }
