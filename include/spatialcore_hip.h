@@ -206,6 +206,18 @@ int sc_nearest_2d(sc_ctx *ctx, const double *xy_targets, int64_t n_targets, cons
                   int64_t n_queries, int32_t *idx_out, double *dist_out);
 int sc_pairwise_2d(sc_ctx *ctx, const double *xy_a, int64_t n_a, const double *xy_b, int64_t n_b,
                    double *mean_out, double *min_out);
+/* sc_nearest_excluding_2d: the same search, but a target whose group code equals the query's excluded code is
+ * skipped (idx -1 / +inf when no target is left): the per-cell "nearest other centroid" loop of
+ * distance.py:305-326 (own domain skipped when source and target column coincide) as ONE launch.
+ * sc_pair_table_2d: all (source group, target group) blocks of the pairwise distance matrix in one launch --
+ * points arrive sorted by group with offsets a_off[n_groups_a + 1], b_off[n_groups_b + 1]; sum_out / min_out are
+ * row-major [n_groups_a][n_groups_b] (sum of distances, minimum distance; +inf / 0 for an empty block).
+ * Replaces the nested `for src ... for tgt ... cdist(...).mean() / .min()` loops of distance.py:329-350, 376-398. */
+int sc_nearest_excluding_2d(sc_ctx *ctx, const double *xy_targets, const int32_t *target_code, int64_t n_targets,
+                            const double *xy_queries, const int32_t *query_excluded_code, int64_t n_queries,
+                            int32_t *idx_out, double *dist_out);
+int sc_pair_table_2d(sc_ctx *ctx, const double *xy_a, const int64_t *a_off, int32_t n_groups_a, const double *xy_b,
+                     const int64_t *b_off, int32_t n_groups_b, double *sum_out, double *min_out);
 
 /* ---- A9: neighbourhood composition --------------------------------------------------------
  * Replaces the per-cell Python counting loops of NB:226-251 on the active graph's pattern:
@@ -221,6 +233,21 @@ int sc_profile_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_t
  * observed counts.  Integer arithmetic, exact. */
 int sc_enrichment_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types, int64_t n_perm,
                          int64_t perm_row0, int64_t *counts_out);
+
+/* ---- multi-GPU: the path's one collective -------------------------------
+ * The reference is single-process (n_jobs=1 hard-coded at AC:580; no collective anywhere).  Here genes shard across
+ * one process per GPU with no data-path communication; at the end ONE ncclAllGather over RCCL (xGMI inside a node)
+ * hands every rank the per-gene rows (I, expected_I, z_score, p_value) of all shards.  RCCL is dlopen'ed on first
+ * use.  Rendezvous: one rank calls sc_comm_unique_id and passes the 128 bytes to the others by any side channel
+ * (spatialcore_amd/parallel.py: a file keyed by the launcher's environment); all ranks call sc_comm_create.
+ * sc_allgather: host arrays; every rank contributes `count` doubles, out holds world * count, in rank order.
+ * sc_allreduce_max: in-place element-wise maximum over ranks (bench: slowest rank's clock; doubles as a barrier). */
+typedef struct sc_comm sc_comm;
+int sc_comm_unique_id(uint8_t *id_out_128);
+int sc_comm_create(sc_ctx *ctx, const uint8_t *id_128, int world, int rank, sc_comm **out);
+int sc_comm_destroy(sc_comm *comm);
+int sc_allgather(sc_comm *comm, const double *local, int64_t count, double *out);
+int sc_allreduce_max(sc_comm *comm, double *values, int64_t count);
 
 #ifdef __cplusplus
 }

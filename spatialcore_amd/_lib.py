@@ -60,8 +60,15 @@ SYMBOLS = {
     "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
     "sc_nearest_2d": [_P, _P, c_int64, _P, c_int64, _P, _P],
     "sc_pairwise_2d": [_P, _P, c_int64, _P, c_int64, POINTER(c_double), POINTER(c_double)],
+    "sc_nearest_excluding_2d": [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
+    "sc_pair_table_2d": [_P, _P, _P, c_int32, _P, _P, c_int32, _P, _P],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
     "sc_enrichment_counts": [_P, _P, c_int64, c_int32, c_int64, c_int64, _P],
+    "sc_comm_unique_id": [_P],
+    "sc_comm_create": [_P, _P, c_int, c_int, POINTER(c_void_p)],
+    "sc_comm_destroy": [_P],
+    "sc_allgather": [_P, _P, c_int64, _P],
+    "sc_allreduce_max": [_P, _P, c_int64],
 }
 
 _lib = None
@@ -392,6 +399,30 @@ class Context:
         _check(self._lib.sc_nearest_2d(self._h, _ptr(t), t.shape[0], _ptr(q), q.shape[0], _ptr(idx), _ptr(dist)))
         return dist, idx
 
+    def nearest_excluding(self, targets, target_code, queries, query_excluded_code):
+        """Nearest target whose group code differs from the query's excluded code; (inf, -1) when none is left."""
+        t, q = _c(targets, np.float64), _c(queries, np.float64)
+        tc, qc = _c(target_code, np.int32), _c(query_excluded_code, np.int32)
+        if tc.size != t.shape[0] or qc.size != q.shape[0]:
+            raise ValueError("one group code per target and per query is required")
+        idx = np.empty(q.shape[0], dtype=np.int32)
+        dist = np.empty(q.shape[0], dtype=np.float64)
+        _check(self._lib.sc_nearest_excluding_2d(self._h, _ptr(t), _ptr(tc), t.shape[0], _ptr(q), _ptr(qc), q.shape[0],
+                                                 _ptr(idx), _ptr(dist)))
+        return dist, idx
+
+    def pair_table(self, a_sorted, a_off, b_sorted, b_off):
+        """(sum, min) of the pairwise distances of every (group of a, group of b) block; points sorted by group."""
+        a, b = _c(a_sorted, np.float64), _c(b_sorted, np.float64)
+        ao, bo = _c(a_off, np.int64), _c(b_off, np.int64)
+        ga, gb = ao.size - 1, bo.size - 1
+        if ao[-1] != a.shape[0] or bo[-1] != b.shape[0]:
+            raise ValueError("group offsets do not cover the point arrays")
+        tot = np.empty((ga, gb), dtype=np.float64)
+        mn = np.empty((ga, gb), dtype=np.float64)
+        _check(self._lib.sc_pair_table_2d(self._h, _ptr(a), _ptr(ao), ga, _ptr(b), _ptr(bo), gb, _ptr(tot), _ptr(mn)))
+        return tot, mn
+
     def pairwise(self, a, b):
         a, b = _c(a, np.float64), _c(b, np.float64)
         mean, mn = c_double(0), c_double(0)
@@ -414,6 +445,56 @@ class Context:
         _check(self._lib.sc_enrichment_counts(self._h, _ptr(lab), lab.size, int(n_types), int(n_perm), int(perm_row0),
                                               _ptr(out)))
         return out
+
+
+class RcclComm:
+    """One rank's end of the RCCL communicator (include/spatialcore_hip.h, "multi-GPU")."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = np.zeros(RcclComm.ID_BYTES, dtype=np.uint8)
+        _check(load_library().sc_comm_unique_id(_ptr(buf)))
+        return buf.tobytes()
+
+    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"an RCCL unique id is {self.ID_BYTES} bytes, got {len(unique_id)}")
+        self._lib = load_library()
+        self._ctx = ctx                     # keeps the context (stream, device) alive
+        self.world, self.rank = int(world), int(rank)
+        h = c_void_p()
+        idb = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        _check(self._lib.sc_comm_create(ctx._h, _ptr(idb), self.world, self.rank, byref(h)))
+        self._h = h
+
+    def all_gather(self, block: np.ndarray) -> np.ndarray:
+        """(world, *block.shape) float64: every rank's equally shaped block, in rank order."""
+        mine = _c(block, np.float64)
+        out = np.empty((self.world,) + mine.shape, dtype=np.float64)
+        if mine.size:
+            _check(self._lib.sc_allgather(self._h, _ptr(mine), mine.size, _ptr(out)))
+        return out
+
+    def max_over_ranks(self, values) -> np.ndarray:
+        v = np.array(values, dtype=np.float64, ndmin=1)
+        _check(self._lib.sc_allreduce_max(self._h, _ptr(v), v.size))
+        return v
+
+    def barrier(self) -> None:
+        self.max_over_ranks([0.0])
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.sc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_ctx = {}

@@ -748,16 +748,21 @@ extern "C" int sc_profile_counts(sc_ctx *c, const int32_t *labels, int64_t n, in
 
 // nearest target of every query: ring walk over the TARGET bin grid (queries may lie outside it).
 // Ties go to the lowest target index.  dist = sqrt(fl(fl(dx*dx)+fl(dy*dy))), as cKDTree.query / cdist.
+// EXCL: a target whose group code equals the query's exclusion code is skipped (idx -1 / +inf when nothing is left).
+template <bool EXCL>
 __global__ __launch_bounds__(256) void k_nearest(const double *__restrict__ sx, const double *__restrict__ sy,
                                                  const int32_t *__restrict__ sid,
                                                  const int32_t *__restrict__ bin_start,
                                                  const double *__restrict__ qxy, int64_t n_q, double x0, double y0,
                                                  double h, int nbx, int nby, int32_t *__restrict__ idx_out,
-                                                 double *__restrict__ dist_out)
+                                                 double *__restrict__ dist_out,
+                                                 const int32_t *__restrict__ tgt_code,
+                                                 const int32_t *__restrict__ q_excl)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_q) return;
     const double qx = qxy[2 * t], qy = qxy[2 * t + 1];
+    const int32_t excl = EXCL ? q_excl[t] : -1;
     const double inv_h = 1.0 / h;
     const int bx = bin_coord(qx, x0, inv_h, nbx), by = bin_coord(qy, y0, inv_h, nby);
     double best = DBL_MAX;
@@ -779,6 +784,7 @@ __global__ __launch_bounds__(256) void k_nearest(const double *__restrict__ sx, 
                     const double dx = qx - sx[s], dy = qy - sy[s];
                     const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
                     const int cid = sid[s];
+                    if (EXCL && tgt_code[cid] == excl) continue;
                     if (cand_better(d, cid, best, best_id)) { best = d; best_id = cid; }
                 }
             }
@@ -793,16 +799,18 @@ __global__ __launch_bounds__(256) void k_nearest(const double *__restrict__ sx, 
         m -= slack;
         if (m > 0.0 && best < m * m) break;
     }
-    idx_out[t] = best_id;
-    dist_out[t] = __dsqrt_rn(best);
+    const bool none = best_id == 0x7fffffff;
+    idx_out[t] = none ? -1 : best_id;
+    dist_out[t] = none ? HUGE_VAL : __dsqrt_rn(best);
 }
 
-extern "C" int sc_nearest_2d(sc_ctx *c, const double *xy_targets, int64_t n_targets, const double *xy_queries,
-                             int64_t n_queries, int32_t *idx_out, double *dist_out)
+static int nearest_impl(sc_ctx *c, const char *who, const double *xy_targets, const int32_t *tgt_code,
+                        int64_t n_targets, const double *xy_queries, const int32_t *q_excl, int64_t n_queries,
+                        int32_t *idx_out, double *dist_out)
 {
-    SC_REQUIRE(c && xy_targets && xy_queries && idx_out && dist_out, SC_ERR_INVALID, "sc_nearest_2d: null pointer");
+    SC_REQUIRE(c && xy_targets && xy_queries && idx_out && dist_out, SC_ERR_INVALID, "%s: null pointer", who);
     SC_REQUIRE(n_targets >= 1 && n_queries >= 1 && n_queries <= 0x7fffffffLL, SC_ERR_INVALID,
-               "sc_nearest_2d: need at least one target and one query");
+               "%s: need at least one target and one query", who);
     SC_HIP(hipSetDevice(c->device));
     c->knn_n = 0;
     c->radius = -1.0;
@@ -815,18 +823,49 @@ extern "C" int sc_nearest_2d(sc_ctx *c, const double *xy_targets, int64_t n_targ
     SC_TRY(c->knn_rd.ensure(sizeof(double) * (size_t)n_queries, &c->mem));
     SC_HIP(hipMemcpyAsync(c->e_tmp_data.p, xy_queries, sizeof(double) * 2 * (size_t)n_queries, hipMemcpyHostToDevice,
                           c->stream));
+    const bool excl = tgt_code && q_excl;
+    if (excl) {
+        SC_TRY(c->e_tmp_indices.ensure(sizeof(int32_t) * (size_t)(n_targets + n_queries), &c->mem));
+        SC_HIP(hipMemcpyAsync(c->e_tmp_indices.p, tgt_code, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice,
+                              c->stream));
+        SC_HIP(hipMemcpyAsync(c->e_tmp_indices.as<int32_t>() + n_targets, q_excl, sizeof(int32_t) * (size_t)n_queries,
+                              hipMemcpyHostToDevice, c->stream));
+    }
     {
         KernelTimerScope ts(c, SC_K_KNN);
-        hipLaunchKernelGGL(k_nearest, dim3((unsigned)ceil_div64(n_queries, 256)), dim3(256), 0, c->stream,
-                           c->sx.as<double>(), c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(),
-                           c->e_tmp_data.as<double>(), n_queries, c->gx0, c->gy0, c->gh, c->nbx, c->nby,
-                           c->knn_idx.as<int32_t>(), c->knn_rd.as<double>());
+        const dim3 grid((unsigned)ceil_div64(n_queries, 256));
+        if (excl)
+            hipLaunchKernelGGL(k_nearest<true>, grid, dim3(256), 0, c->stream, c->sx.as<double>(), c->sy.as<double>(),
+                               c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), c->e_tmp_data.as<double>(), n_queries,
+                               c->gx0, c->gy0, c->gh, c->nbx, c->nby, c->knn_idx.as<int32_t>(), c->knn_rd.as<double>(),
+                               c->e_tmp_indices.as<int32_t>(), c->e_tmp_indices.as<int32_t>() + n_targets);
+        else
+            hipLaunchKernelGGL(k_nearest<false>, grid, dim3(256), 0, c->stream, c->sx.as<double>(), c->sy.as<double>(),
+                               c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), c->e_tmp_data.as<double>(), n_queries,
+                               c->gx0, c->gy0, c->gh, c->nbx, c->nby, c->knn_idx.as<int32_t>(), c->knn_rd.as<double>(),
+                               (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
     SC_HIP(hipGetLastError());
     SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * (size_t)n_queries, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipMemcpyAsync(dist_out, c->knn_rd.p, sizeof(double) * (size_t)n_queries, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
+}
+
+extern "C" int sc_nearest_2d(sc_ctx *c, const double *xy_targets, int64_t n_targets, const double *xy_queries,
+                             int64_t n_queries, int32_t *idx_out, double *dist_out)
+{
+    return nearest_impl(c, "sc_nearest_2d", xy_targets, nullptr, n_targets, xy_queries, nullptr, n_queries, idx_out,
+                        dist_out);
+}
+
+extern "C" int sc_nearest_excluding_2d(sc_ctx *c, const double *xy_targets, const int32_t *target_code,
+                                       int64_t n_targets, const double *xy_queries, const int32_t *query_excluded_code,
+                                       int64_t n_queries, int32_t *idx_out, double *dist_out)
+{
+    SC_REQUIRE(target_code && query_excluded_code, SC_ERR_INVALID, "sc_nearest_excluding_2d: null code array");
+    return nearest_impl(c, "sc_nearest_excluding_2d", xy_targets, target_code, n_targets, xy_queries,
+                        query_excluded_code, n_queries, idx_out, dist_out);
 }
 
 // brute-force pairwise euclidean distances between two point sets, LDS-tiled: block = 256 points of A
@@ -895,6 +934,108 @@ extern "C" int sc_pairwise_2d(sc_ctx *c, const double *xy_a, int64_t n_a, const 
     for (int k = 0; k < blocks; ++k) { s += h[2 * k]; m = h[2 * k + 1] < m ? h[2 * k + 1] : m; }
     if (mean_out) *mean_out = s / ((double)n_a * (double)n_b);
     if (min_out) *min_out = m;
+    return SC_OK;
+}
+
+// Every (source group, target group) block of the all-pairs distance matrix in one launch: the A points are sorted by
+// group and cut into chunks of <= 256 points that never straddle a group; workgroup (chunk, t) streams target group
+// t through LDS and leaves {sum, min} of its block.  Replaces the reference's per-pair cdist(src, tgt).mean()/.min()
+// loops (distance.py:266-270, 340-350, 387-398).
+__global__ __launch_bounds__(256) void k_pair_table(const double *__restrict__ a, const int64_t *__restrict__ chunk_a0,
+                                                    const int32_t *__restrict__ chunk_cnt,
+                                                    const double *__restrict__ b, const int64_t *__restrict__ b_off,
+                                                    int n_groups_b, double *__restrict__ partial)
+{
+    __shared__ double2 tile[PW_BTILE];
+    __shared__ double red_s[256], red_m[256];
+    const int64_t a0 = chunk_a0[blockIdx.x];
+    const bool live = (int)threadIdx.x < chunk_cnt[blockIdx.x];
+    const double ax = live ? a[2 * (a0 + threadIdx.x)] : 0.0, ay = live ? a[2 * (a0 + threadIdx.x) + 1] : 0.0;
+    const int64_t b0 = b_off[blockIdx.y], b1 = b_off[blockIdx.y + 1];
+    double sum = 0.0, mn = DBL_MAX;
+    for (int64_t j0 = b0; j0 < b1; j0 += PW_BTILE) {
+        const int cnt = (int)(b1 - j0 < PW_BTILE ? b1 - j0 : PW_BTILE);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) tile[k] = reinterpret_cast<const double2 *>(b)[j0 + k];
+        __syncthreads();
+        if (live) {
+            for (int k = 0; k < cnt; ++k) {
+                const double dx = ax - tile[k].x, dy = ay - tile[k].y;
+                const double d = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+                sum += d;
+                mn = d < mn ? d : mn;
+            }
+        }
+    }
+    red_s[threadIdx.x] = sum;
+    red_m[threadIdx.x] = mn;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red_s[threadIdx.x] += red_s[threadIdx.x + s];
+            red_m[threadIdx.x] = red_m[threadIdx.x + s] < red_m[threadIdx.x] ? red_m[threadIdx.x + s] : red_m[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double *o = partial + 2 * ((int64_t)blockIdx.x * n_groups_b + blockIdx.y);
+        o[0] = red_s[0];
+        o[1] = red_m[0];
+    }
+}
+
+extern "C" int sc_pair_table_2d(sc_ctx *c, const double *xy_a, const int64_t *a_off, int32_t n_groups_a,
+                                const double *xy_b, const int64_t *b_off, int32_t n_groups_b, double *sum_out,
+                                double *min_out)
+{
+    SC_REQUIRE(c && xy_a && xy_b && a_off && b_off && sum_out && min_out, SC_ERR_INVALID, "sc_pair_table_2d: null pointer");
+    SC_REQUIRE(n_groups_a >= 1 && n_groups_b >= 1 && n_groups_b <= 65535, SC_ERR_INVALID,
+               "sc_pair_table_2d: group counts out of range (%d, %d)", n_groups_a, n_groups_b);
+    SC_REQUIRE(a_off[0] == 0 && b_off[0] == 0, SC_ERR_INVALID, "sc_pair_table_2d: offsets must start at 0");
+    for (int g = 0; g < n_groups_a; ++g)
+        SC_REQUIRE(a_off[g + 1] >= a_off[g], SC_ERR_INVALID, "sc_pair_table_2d: source offsets not monotone");
+    for (int g = 0; g < n_groups_b; ++g)
+        SC_REQUIRE(b_off[g + 1] >= b_off[g], SC_ERR_INVALID, "sc_pair_table_2d: target offsets not monotone");
+    const int64_t n_a = a_off[n_groups_a], n_b = b_off[n_groups_b];
+    SC_REQUIRE(n_a >= 1 && n_b >= 1, SC_ERR_INVALID, "sc_pair_table_2d: empty point set");
+    SC_HIP(hipSetDevice(c->device));
+    std::vector<int64_t> ch0;
+    std::vector<int32_t> chn, chg;
+    for (int g = 0; g < n_groups_a; ++g)
+        for (int64_t p = a_off[g]; p < a_off[g + 1]; p += 256) {
+            ch0.push_back(p);
+            chn.push_back((int32_t)(a_off[g + 1] - p < 256 ? a_off[g + 1] - p : 256));
+            chg.push_back(g);
+        }
+    const size_t chunks = ch0.size();
+    SC_REQUIRE(chunks <= 0x7fffffffULL, SC_ERR_INVALID, "sc_pair_table_2d: too many points");
+    SC_TRY(c->e_tmp_data.ensure(sizeof(double) * 2 * (size_t)(n_a + n_b), &c->mem));
+    SC_TRY(c->e_tmp_indptr.ensure(sizeof(int64_t) * (chunks + (size_t)n_groups_b + 1), &c->mem));
+    SC_TRY(c->e_tmp_indices.ensure(sizeof(int32_t) * chunks, &c->mem));
+    SC_TRY(c->red_tmp.ensure(sizeof(double) * 2 * chunks * (size_t)n_groups_b, &c->mem));
+    double *da = c->e_tmp_data.as<double>(), *db = da + 2 * n_a;
+    int64_t *d_ch0 = c->e_tmp_indptr.as<int64_t>(), *d_boff = d_ch0 + chunks;
+    SC_HIP(hipMemcpyAsync(da, xy_a, sizeof(double) * 2 * (size_t)n_a, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(db, xy_b, sizeof(double) * 2 * (size_t)n_b, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(d_ch0, ch0.data(), sizeof(int64_t) * chunks, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(d_boff, b_off, sizeof(int64_t) * (size_t)(n_groups_b + 1), hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(c->e_tmp_indices.p, chn.data(), sizeof(int32_t) * chunks, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pair_table, dim3((unsigned)chunks, (unsigned)n_groups_b), dim3(256), 0, c->stream, da, d_ch0,
+                       c->e_tmp_indices.as<int32_t>(), db, d_boff, (int)n_groups_b, c->red_tmp.as<double>());
+    SC_HIP(hipGetLastError());
+    std::vector<double> h(2 * chunks * (size_t)n_groups_b);
+    SC_HIP(hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    // chunks of a group are reduced in ascending order: run-to-run reproducible
+    for (int64_t k = 0; k < (int64_t)n_groups_a * n_groups_b; ++k) { sum_out[k] = 0.0; min_out[k] = HUGE_VAL; }
+    for (size_t ch = 0; ch < chunks; ++ch)
+        for (int t = 0; t < n_groups_b; ++t) {
+            if (b_off[t + 1] == b_off[t]) continue;
+            const size_t o = (size_t)chg[ch] * n_groups_b + t;
+            sum_out[o] += h[2 * (ch * n_groups_b + t)];
+            const double m = h[2 * (ch * n_groups_b + t) + 1];
+            if (m < min_out[o]) min_out[o] = m;
+        }
     return SC_OK;
 }
 

@@ -226,18 +226,21 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const double *__restrict
     if (threadIdx.x < 16) partial[(tile * gridDim.x + blockIdx.x) * SC_TILE + threadIdx.x] = sh[threadIdx.x];
 }
 
-// out[tile*16+slot] = (sum over chunks, ascending) * mul
-__global__ void k_colsum_final(const double *__restrict__ partial, double *__restrict__ out, int chunks,
-                               double mul)
+// out[tile*16+slot] = (sum over chunks, ascending) / div; out_raw (optional) gets the sum itself.
+// A true division, as numpy's mean takes it: sum * (1/n) turns a constant column c into c(1 +- eps) for ~15 % of
+// the cell counts n, and a zero-variance gene would then look alive.
+__global__ void k_colsum_final(const double *__restrict__ partial, double *__restrict__ out,
+                               double *__restrict__ out_raw, int chunks, double div)
 {
     int tile = blockIdx.x, slot = threadIdx.x;
     double s = 0.0;
     for (int ch = 0; ch < chunks; ++ch) s += partial[((int64_t)tile * chunks + ch) * SC_TILE + slot];
-    out[tile * SC_TILE + slot] = s * mul;
+    if (out_raw) out_raw[tile * SC_TILE + slot] = s;
+    out[tile * SC_TILE + slot] = s / div;
 }
 
 template <int OP>
-static int colsum(sc_ctx *c, const double *A, const double *B, double *out, double mul)
+static int colsum(sc_ctx *c, const double *A, const double *B, double *out, double div, double *out_raw = nullptr)
 {
     int64_t n = c->e_n;
     int chunks = (int)ceil_div64(n, RED_ROWS_PER_BLOCK);
@@ -245,7 +248,7 @@ static int colsum(sc_ctx *c, const double *A, const double *B, double *out, doub
     hipLaunchKernelGGL(k_colsum_partial<OP>, dim3(chunks, (unsigned)c->e_tiles), dim3(256), 0, c->stream, A, B,
                        c->red_tmp.as<double>(), n);
     hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)c->e_tiles), dim3(SC_TILE), 0, c->stream,
-                       c->red_tmp.as<double>(), out, chunks, mul);
+                       c->red_tmp.as<double>(), out, out_raw, chunks, div);
     SC_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -281,12 +284,11 @@ static int expr_center(sc_ctx *c)
     SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "no expression loaded (call sc_expr_set_* first)");
     int64_t n = c->e_n;
     SC_TRY(c->Z.ensure((size_t)c->e_tiles * n * SC_TILE * sizeof(double), &c->mem));
-    SC_TRY(colsum<OP_ID>(c, c->X.as<double>(), nullptr, c->g_mean.as<double>(), 1.0 / (double)n));
+    SC_TRY(colsum<OP_ID>(c, c->X.as<double>(), nullptr, c->g_mean.as<double>(), (double)n));
     dim3 grid((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)c->e_tiles);
     hipLaunchKernelGGL(k_center, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->g_mean.as<double>(),
                        c->Z.as<double>(), n);
-    SC_TRY(colsum<OP_SQ>(c, c->Z.as<double>(), nullptr, c->g_z2.as<double>(), 1.0));
-    SC_TRY(colsum<OP_SQ>(c, c->Z.as<double>(), nullptr, c->g_var.as<double>(), 1.0 / (double)n));
+    SC_TRY(colsum<OP_SQ>(c, c->Z.as<double>(), nullptr, c->g_var.as<double>(), (double)n, c->g_z2.as<double>()));
     SC_HIP(hipGetLastError());
     return SC_OK;
 }

@@ -1,22 +1,33 @@
-"""Gene sharding across the GPUs of one node.
+"""Gene sharding across the GPUs of one node; no PyTorch anywhere.
 
 The path shards embarrassingly: rank r owns a contiguous slice of the gene list, builds the same
 graph and the same permutation table (same seed) on its own GPU, and there is no data-path
-collective.  One all-gather of the small per-gene result table (I, z, p) at the end makes the full
-table available on every rank -- over RCCL/xGMI when the process group's backend is "nccl"
-(which is RCCL on ROCm), over gloo in the CPU tests.
+collective.  ONE all-gather of the small per-gene result rows (I, expected_I, z, p) at the end makes
+the full table available on every rank: ``sc_allgather`` = ``ncclAllGather`` over RCCL (xGMI inside a
+node), reached through the C ABI like everything else (``_lib.RcclComm``).
 
-torch is imported lazily and only here: it provides the process group (launch contract of
-``torch.distributed.run``), nothing on the compute path.
+Launch contract: one process per GPU with ``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` (and, for the
+rendezvous name, ``MASTER_PORT``) in the environment -- what ``python -m torch.distributed.run``,
+``mpirun`` wrappers or a plain shell loop provide.  The 128-byte RCCL id travels from rank 0 to the
+others through a small file (``rendezvous_file()``).
+
+``FileComm`` moves the same blocks through files instead of RCCL.  It exists for rehearsing the
+N > 1 code path where RCCL cannot run -- several ranks sharing ONE GPU (RCCL refuses duplicate
+devices) or no GPU at all (CPU tests of the shard/merge logic) -- and is only used when asked for
+(``SC_COMM_TRANSPORT=file`` or an explicit ``comm=``).  It is a transport, not a compute fallback.
 """
 
 from __future__ import annotations
 
 import os
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import pandas as pd
+
+_RESULT_COLUMNS = ["I", "expected_I", "z_score", "p_value"]
+_connects = 0   # communicators opened by this process (all ranks open them in the same order)
 
 
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
@@ -28,73 +39,197 @@ def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def _dist():
-    import torch.distributed as dist
-
-    return dist if dist.is_available() and dist.is_initialized() else None
-
-
 def world_info() -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the process group if initialised, else from the env."""
-    d = _dist()
-    if d is not None:
-        return d.get_rank(), d.get_world_size(), int(os.environ.get("LOCAL_RANK", d.get_rank()))
-    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    """(rank, world, local_rank) from the launcher's environment (1 process = 1 GPU)."""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    return rank, world, int(os.environ.get("LOCAL_RANK", rank))
 
 
-def all_gather_rows(local: np.ndarray, n_total: int) -> np.ndarray:
-    """All-gather a (rows_local, F) float64 block whose row ranges follow ``shard_bounds``."""
-    d = _dist()
+def _launcher_identity() -> str:
+    """Same string in every rank of one launch, different across launches: the parent process (the
+    launcher all ranks were forked from) with its start time, plus the rendezvous port."""
+    ppid = os.getppid()
+    started = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            started = f.read().rsplit(")", 1)[1].split()[19]   # field 22: start time in clock ticks
+    except (OSError, IndexError):
+        pass
+    return f"{os.getuid()}_{ppid}_{started}_{os.environ.get('MASTER_PORT', '0')}"
+
+
+def rendezvous_file(seq: int = 0) -> str:
+    """Where rank 0 leaves the RCCL id for the other ranks (``SC_RENDEZVOUS_FILE`` overrides)."""
+    base = os.environ.get("SC_RENDEZVOUS_FILE")
+    if not base:
+        base = os.path.join(os.environ.get("SC_RENDEZVOUS_DIR", "/tmp"), f"sc_rccl_{_launcher_identity()}")
+    return f"{base}.{seq}"
+
+
+def _publish(path: str, payload: bytes) -> None:
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(payload)
+    os.replace(tmp, path)        # atomic: a reader sees nothing or everything
+
+
+def _await_file(path: str, timeout_s: float) -> bytes:
+    deadline = time.monotonic() + timeout_s
+    while True:
+        try:
+            with open(path, "rb") as f:
+                return f.read()
+        except FileNotFoundError:
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous file {path} did not appear within {timeout_s:.0f}s") from None
+            time.sleep(0.005)
+
+
+class FileComm:
+    """All-gather through a directory (rehearsal / CPU tests only; see the module docstring)."""
+
+    def __init__(self, directory: str, world: int, rank: int, timeout_s: float = 300.0):
+        self.world, self.rank, self._dir, self._round, self._timeout = int(world), int(rank), directory, 0, timeout_s
+        os.makedirs(directory, exist_ok=True)
+
+    def _name(self, rnd: int, rank: int) -> str:
+        return os.path.join(self._dir, f"{rnd}_{rank}.bin")
+
+    def all_gather(self, block: np.ndarray) -> np.ndarray:
+        mine = np.ascontiguousarray(block, dtype=np.float64)
+        rnd = self._round
+        _publish(self._name(rnd, self.rank), mine.tobytes())
+        out = np.empty((self.world,) + mine.shape, dtype=np.float64)
+        for r in range(self.world):
+            raw = mine.tobytes() if r == self.rank else _await_file(self._name(rnd, r), self._timeout)
+            out[r] = np.frombuffer(raw, dtype=np.float64).reshape(mine.shape)
+        # everybody has written round `rnd`, hence finished reading round `rnd - 1`
+        if rnd > 0:
+            try:
+                os.unlink(self._name(rnd - 1, self.rank))
+            except OSError:
+                pass
+        self._round += 1
+        return out
+
+    def max_over_ranks(self, values) -> np.ndarray:
+        return self.all_gather(np.array(values, dtype=np.float64, ndmin=1)).max(axis=0)
+
+    def barrier(self) -> None:
+        self.all_gather(np.zeros(1))
+
+    def close(self) -> None:
+        try:
+            os.unlink(self._name(self._round - 1, self.rank))
+        except OSError:
+            pass
+
+
+class _SoloComm:
+    world, rank = 1, 0
+
+    def all_gather(self, block):
+        return np.ascontiguousarray(block, dtype=np.float64)[None]
+
+    def max_over_ranks(self, values):
+        return np.array(values, dtype=np.float64, ndmin=1)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def connect(ctx=None, transport: Optional[str] = None, timeout_s: float = 300.0):
+    """Communicator of this rank among ``WORLD_SIZE`` ranks.
+
+    ``transport``: ``"rccl"`` (default; needs ``ctx``, the rank's ``_lib.Context`` on its own GPU) or
+    ``"file"`` (``FileComm``); ``SC_COMM_TRANSPORT`` sets the default.  Every rank must call this the
+    same number of times in the same order."""
+    global _connects
+    rank, world, _ = world_info()
+    if world == 1:
+        return _SoloComm()
+    transport = transport or os.environ.get("SC_COMM_TRANSPORT", "rccl")
+    seq, _connects = _connects, _connects + 1
+    path = rendezvous_file(seq)
+    if transport == "file":
+        return FileComm(path + ".d", world, rank, timeout_s)
+    if transport != "rccl":
+        raise ValueError(f"unknown transport '{transport}' (expected 'rccl' or 'file')")
+    if ctx is None:
+        raise ValueError("the RCCL transport needs the rank's GPU context")
+    from spatialcore_amd import _lib
+
+    if rank == 0:
+        uid = _lib.RcclComm.unique_id()
+        _publish(path, uid)
+    else:
+        uid = _await_file(path, timeout_s)
+    comm = _lib.RcclComm(ctx, uid, world, rank)     # returns once every rank has joined, i.e. has read the id
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return comm
+
+
+def all_gather_rows(local: np.ndarray, n_total: int, comm) -> np.ndarray:
+    """All-gather (rows_local, F) float64 blocks whose row ranges follow ``shard_bounds``: blocks are padded
+    to the longest shard (the collective wants equal counts) and trimmed again on arrival."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if d is None or d.get_world_size() == 1:
+    world = comm.world
+    if world == 1:
         return local
-    import torch
-
-    world, rank = d.get_world_size(), d.get_rank()
-    width = local.shape[1]
-    longest = max(b - a for a, b in (shard_bounds(n_total, world, r) for r in range(world)))
-    pad = np.zeros((longest, width), dtype=np.float64)
-    pad[: local.shape[0]] = local
-    on_gpu = d.get_backend() == "nccl"
-    mine = torch.from_numpy(pad)
-    if on_gpu:
-        mine = mine.cuda()
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    d.all_gather(parts, mine)  # the single collective of the path
-    out = np.empty((n_total, width), dtype=np.float64)
-    for r, part in enumerate(parts):
-        a, b = shard_bounds(n_total, world, r)
-        out[a:b] = part.cpu().numpy()[: b - a]
-    return out
+    spans = [shard_bounds(n_total, world, r) for r in range(world)]
+    longest = max(b - a for a, b in spans)
+    padded = np.zeros((longest, local.shape[1]), dtype=np.float64)
+    padded[: local.shape[0]] = local
+    parts = comm.all_gather(padded)                  # the single collective of the path
+    return np.concatenate([parts[r, : b - a] for r, (a, b) in enumerate(spans)], axis=0)
 
 
-def morans_i_sharded(adata, genes: Optional[Sequence[str]] = None, key_added: str = "morans_i",
-                     compute: Optional[Callable] = None, **kwargs):
-    """``morans_i`` with the gene list sharded over the ranks of the current process group.
+def morans_i_sharded(adata, genes: Optional[Sequence[str]] = None, key_added: str = "morans_i", copy: bool = False,
+                     compute: Optional[Callable] = None, comm=None, device: Optional[int] = None, **kwargs):
+    """``morans_i`` with the gene list sharded over the ranks of the launch.
 
     Every rank ends with the complete ``adata.uns[key_added]`` table (input gene order), identical
     to an unsharded call: the permutation table depends only on ``seed`` and ``n_cells``, so each
-    gene sees the same permutations whichever rank computes it.  ``compute`` defaults to the HIP
-    ``morans_i`` on GPU ``LOCAL_RANK``; tests inject a CPU checker to exercise the shard/merge logic.
+    gene sees the same permutations whichever rank computes it.  ``kwargs`` go to ``morans_i``
+    (``n_neighbors``, ``n_permutations``, ``seed``, ``layer``, ``spatial_key``, ``use_existing_graph``).
+    ``device`` defaults to ``LOCAL_RANK``; ``comm`` defaults to ``connect()`` on that device's context
+    and is then closed before returning.  ``compute(adata, gene_list, **kwargs) -> DataFrame`` replaces
+    the per-shard HIP call in the CPU tests of the shard/merge logic.
     """
     rank, world, local_rank = world_info()
+    device = local_rank if device is None else int(device)
+    if copy:
+        adata = adata.copy()
     names: List[str] = list(adata.var_names) if genes is None else ([genes] if isinstance(genes, str) else list(genes))
-    lo, hi = shard_bounds(len(names), world, rank)
+    own_comm = comm is None
     if compute is None:
+        from spatialcore_amd import _lib
         from spatialcore_amd.spatial.autocorrelation import morans_i
 
         def compute(ad, gene_list, **kw):
-            return morans_i(ad, genes=gene_list, key_added="_shard", device=local_rank, **kw).uns.pop("_shard")
+            return morans_i(ad, genes=gene_list, key_added="_shard", device=device, **kw).uns.pop("_shard")
 
+        if own_comm:
+            comm = connect(_lib.default_context(device))
+    elif own_comm:
+        comm = connect(None, transport=os.environ.get("SC_COMM_TRANSPORT", "file"))
+    lo, hi = shard_bounds(len(names), comm.world, comm.rank)
     mine = names[lo:hi]
-    cols = ["I", "expected_I", "z_score", "p_value"]
     if mine:
-        df = compute(adata, mine, **kwargs)
-        local = df[cols].to_numpy(dtype=np.float64)
+        local = compute(adata, mine, **kwargs)[_RESULT_COLUMNS].to_numpy(dtype=np.float64)
     else:
-        local = np.zeros((0, len(cols)))
-    full = all_gather_rows(local, len(names))
-    table = pd.DataFrame(full, columns=cols)
+        local = np.zeros((0, len(_RESULT_COLUMNS)))
+    full = all_gather_rows(local, len(names), comm)
+    if own_comm:
+        comm.close()
+    table = pd.DataFrame(full, columns=_RESULT_COLUMNS)
     table.insert(0, "gene", names)
     adata.uns[key_added] = table
     return adata

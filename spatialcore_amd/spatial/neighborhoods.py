@@ -12,12 +12,63 @@ from __future__ import annotations
 from typing import Optional
 
 import numpy as np
+import pandas as pd
 
 from spatialcore_amd import _lib
 from spatialcore_amd._logging import get_logger
 from spatialcore_amd._metadata import update_metadata
 
 logger = get_logger("spatial.neighborhoods")
+
+
+def _request_problem(adata, celltype_column, method, k, radius, spatial_key) -> Optional[str]:
+    """The first thing wrong with a request, as the reference words it (NB:146-179), else None."""
+    if spatial_key not in adata.obsm:
+        return (f"adata.obsm['{spatial_key}'] not found. "
+                "Spatial coordinates are required for neighborhood computation.")
+    if celltype_column not in adata.obs.columns:
+        return (f"Column '{celltype_column}' not found in adata.obs. "
+                f"Available columns: {list(adata.obs.columns)[:10]}...")
+    per_method = {
+        "knn": lambda: (f"k must be >= 1, got {k}" if k < 1 else
+                        f"k must be < number of cells ({adata.n_obs}), got {k}" if k >= adata.n_obs else None),
+        "radius": lambda: ("'radius' must be provided when method='radius'." if radius is None else
+                           f"radius must be > 0, got {radius}" if radius <= 0 else None),
+    }
+    if method not in per_method:
+        return f"Invalid method: '{method}'. Must be 'knn' or 'radius'."
+    return per_method[method]()
+
+
+def _label_codes(adata, celltype_column: str):
+    """Sorted unique labels (NB:196) and the int32 code of every cell; missing labels are an error (NB:186-192)."""
+    labels = adata.obs[celltype_column]
+    n_missing = int(labels.isna().sum())
+    if n_missing:
+        raise ValueError(f"{n_missing} cells have missing labels in '{celltype_column}'. "
+                         "Fill or remove missing labels before computing neighborhoods.")
+    codes, kinds = pd.factorize(np.asarray(labels.values, dtype=object), sort=True)
+    return list(kinds), codes.astype(np.int32)
+
+
+def _coordinates(adata, spatial_key: str) -> np.ndarray:
+    xy = np.asarray(adata.obsm[spatial_key])
+    if xy.ndim != 2 or xy.shape[1] != 2:
+        raise ValueError("only 2-D coordinates are supported by the MI355X path "
+                         f"(adata.obsm['{spatial_key}'] has shape {xy.shape})")
+    return np.ascontiguousarray(xy, dtype=np.float64)
+
+
+def _activate_neighbour_graph(ctx, coords: np.ndarray, method: str, k: int, radius) -> None:
+    """Exact kNN (NB:213-228) or closed-ball radius lists (NB:241-251) as the context's unweighted graph."""
+    if method == "knn":
+        logger.debug(f"Querying {k} nearest neighbors per cell")
+        ctx.knn(coords, k, fetch=False)
+        ctx.graph_from_knn(1.0)
+    else:
+        logger.debug(f"Querying neighbors within radius={radius}")
+        indptr, indices = ctx.radius_graph(coords, float(radius))
+        ctx.set_graph_csr(indptr, indices, np.ones(indices.size), coords.shape[0])
 
 
 def compute_neighborhood_profile(
@@ -34,52 +85,22 @@ def compute_neighborhood_profile(
     device: int = 0,
 ):
     """Cell-type composition of every cell's spatial neighbourhood (NB:48-296)."""
-    if spatial_key not in adata.obsm:
-        raise ValueError(f"adata.obsm['{spatial_key}'] not found. "
-                         "Spatial coordinates are required for neighborhood computation.")
-    if celltype_column not in adata.obs.columns:
-        raise ValueError(f"Column '{celltype_column}' not found in adata.obs. "
-                         f"Available columns: {list(adata.obs.columns)[:10]}...")
-    if method not in ["knn", "radius"]:
-        raise ValueError(f"Invalid method: '{method}'. Must be 'knn' or 'radius'.")
+    problem = _request_problem(adata, celltype_column, method, k, radius, spatial_key)
+    if problem:
+        raise ValueError(problem)
+    if copy:
+        adata = adata.copy()
     n_cells = adata.n_obs
-    if method == "knn" and k < 1:
-        raise ValueError(f"k must be >= 1, got {k}")
-    if method == "knn" and k >= n_cells:
-        raise ValueError(f"k must be < number of cells ({n_cells}), got {k}")
-    if method == "radius":
-        if radius is None:
-            raise ValueError("'radius' must be provided when method='radius'.")
-        if radius <= 0:
-            raise ValueError(f"radius must be > 0, got {radius}")
-
-    adata = adata.copy() if copy else adata
-    coords = np.ascontiguousarray(np.asarray(adata.obsm[spatial_key])[:, :2], dtype=np.float64)
-
-    celltype_series = adata.obs[celltype_column]
-    if celltype_series.isna().any():
-        n_missing = int(celltype_series.isna().sum())
-        raise ValueError(f"{n_missing} cells have missing labels in '{celltype_column}'. "
-                         "Fill or remove missing labels before computing neighborhoods.")
-    unique_celltypes = sorted(celltype_series.unique())
+    unique_celltypes, codes = _label_codes(adata, celltype_column)
     n_celltypes = len(unique_celltypes)
     if n_celltypes < 2:
         raise ValueError(f"At least 2 unique cell types required, found {n_celltypes}. "
                          f"Check column '{celltype_column}'.")
-    code_of = {ct: i for i, ct in enumerate(unique_celltypes)}
-    codes = np.fromiter((code_of[v] for v in celltype_series.values), dtype=np.int32, count=n_cells)
-
+    coords = _coordinates(adata, spatial_key)
     logger.info(f"Computing neighborhood profiles: {n_cells:,} cells, {n_celltypes} cell types, method={method}")
 
     ctx = _lib.default_context(device)
-    if method == "knn":
-        logger.debug(f"Querying {k} nearest neighbors per cell")
-        ctx.knn(coords, k, fetch=False)
-        ctx.graph_from_knn(1.0)
-    else:
-        logger.debug(f"Querying neighbors within radius={radius}")
-        indptr, indices = ctx.radius_graph(coords, float(radius))
-        ctx.set_graph_csr(indptr, indices, np.ones(indices.size), n_cells)
+    _activate_neighbour_graph(ctx, coords, method, k, radius)
     try:
         neighborhood_profile = ctx.profile_counts(codes, n_celltypes)
     except ValueError as e:
@@ -141,41 +162,22 @@ def neighborhood_enrichment(
     ``count``, ``mean``, ``std`` (population), ``zscore = (count - mean) / std``,
     ``p_value = (#{perm count >= count} + 1) / (P + 1)`` as (T, T) arrays and ``celltypes``.
     """
-    if spatial_key not in adata.obsm:
-        raise ValueError(f"adata.obsm['{spatial_key}'] not found. "
-                         "Spatial coordinates are required for neighborhood computation.")
-    if celltype_column not in adata.obs.columns:
-        raise ValueError(f"Column '{celltype_column}' not found in adata.obs. "
-                         f"Available columns: {list(adata.obs.columns)[:10]}...")
-    if method not in ["knn", "radius"]:
-        raise ValueError(f"Invalid method: '{method}'. Must be 'knn' or 'radius'.")
-    n_cells = adata.n_obs
-    if method == "knn" and not (1 <= k < n_cells):
-        raise ValueError(f"k must be >= 1 and < number of cells ({n_cells}), got {k}")
-    if method == "radius" and (radius is None or radius <= 0):
-        raise ValueError(f"radius must be > 0 when method='radius', got {radius}")
+    problem = _request_problem(adata, celltype_column, method, k, radius, spatial_key)
+    if problem:
+        raise ValueError(problem)
     if n_permutations < 0:
         raise ValueError(f"n_permutations must be >= 0, got {n_permutations}")
-    adata = adata.copy() if copy else adata
-    coords = np.ascontiguousarray(np.asarray(adata.obsm[spatial_key])[:, :2], dtype=np.float64)
-    series = adata.obs[celltype_column]
-    if series.isna().any():
-        raise ValueError(f"{int(series.isna().sum())} cells have missing labels in '{celltype_column}'. "
-                         "Fill or remove missing labels before computing neighborhoods.")
-    celltypes = sorted(series.unique())
-    code_of = {ct: i for i, ct in enumerate(celltypes)}
-    codes = np.fromiter((code_of[v] for v in series.values), dtype=np.int32, count=n_cells)
+    if copy:
+        adata = adata.copy()
+    n_cells = adata.n_obs
+    celltypes, codes = _label_codes(adata, celltype_column)
+    coords = _coordinates(adata, spatial_key)
     T = len(celltypes)
     logger.info(f"Computing neighborhood enrichment: {n_cells:,} cells, {T} cell types, method={method}, "
                 f"permutations={n_permutations}")
 
     ctx = _lib.default_context(device)
-    if method == "knn":
-        ctx.knn(coords, k, fetch=False)
-        ctx.graph_from_knn(1.0)
-    else:
-        indptr, indices = ctx.radius_graph(coords, float(radius))
-        ctx.set_graph_csr(indptr, indices, np.ones(indices.size), n_cells)
+    _activate_neighbour_graph(ctx, coords, method, k, radius)
 
     words = _lib.rng_state_words(np.random.default_rng(seed))
     observed = None

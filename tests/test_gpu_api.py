@@ -94,6 +94,25 @@ def test_lees_l_golden():
         assert one["p_value"] == float(g[f"c{ci}_single_p"])
 
 
+def test_lees_l_constant_gene_at_awkward_cell_count(oracle):
+    """n = 501 cells (501 * fl(1/501) != 1): a gene constant at 1.0 must be zero-variance -> L = 0, p = 1, NO draws
+    from the shared stream (AC:1129-1140), so the later pair's p-value is what it is without that pair."""
+    from spatialcore_amd.spatial import lees_l, morans_i
+
+    coords, X = synth(501, 4, 8, dtype=np.float64, sparse_x=False)
+    X[:, 1] = 1.0
+    ad = make_adata(coords, X)
+    res = lees_l(ad, gene_pairs=[("g0", "g1"), ("g2", "g3")], n_neighbors=6, n_permutations=99, seed=3)
+    assert res[0]["L"] == 0.0 and res[0]["p_value"] == 1.0
+    alone = lees_l(ad, gene_pairs=[("g2", "g3")], n_neighbors=6, n_permutations=99, seed=3)
+    assert res[1] == alone[0]
+    want = oracle.lees_l(coords, X, [(0, 1), (2, 3)], 6, 99, 3)
+    assert want[0]["L"] == 0.0 and want[0]["p_value"] == 1.0
+    assert res[1]["p_value"] == want[1]["p_value"] and res[1]["L"] == pytest.approx(want[1]["L"], rel=1e-9)
+    morans_i(ad, genes=["g0", "g1"], n_neighbors=6, n_permutations=9)
+    assert np.isnan(ad.uns["morans_i"]["I"].values[1])
+
+
 def test_neighborhood_profile_golden():
     from spatialcore_amd.spatial import compute_neighborhood_profile
 

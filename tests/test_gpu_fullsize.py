@@ -105,6 +105,45 @@ def test_moran_1m_invariants(big, oracle):
     np.testing.assert_allclose(got["sims"][0, :2], oracle.morans_i_sims_gather(g, vals, perm1)[0], rtol=1e-9)
 
 
+def test_config1_at_size_bench_path_p1000(big, oracle):
+    """BASELINE configs[1] at size, the path bench.py times: 1M cells, 64 genes, k = 15, P = 1000 through
+    sc_moran_seeded (block-parallel generator, chunk schedule 32+40 / 128 x 7 / 64, inverse-only tables, CU-masked
+    scoring stream).  Every statistic bit-equal to the two-step path fed with the HOST generator's table; an oracle
+    slice (2 genes: observed I + 3 permutation rows) ties both to the CPU restatement."""
+    from scipy.sparse import csr_matrix
+    from spatialcore_amd import _lib
+
+    ctx, coords, _ = big
+    G, P = 64, 1000
+    rng = np.random.default_rng(7)
+    lam = np.exp(rng.uniform(np.log(0.05), np.log(5.0), G))
+    X = rng.poisson(lam, (N, G)).astype(np.float32)
+    X[:, ::2] += (2.0 * (1 + np.sin(coords[:, 1:2] / 700.0))).astype(np.float32)
+    nbr = ctx.knn(coords, K)
+    ctx.graph_from_knn(1.0 / K)
+    ctx.set_expression(X, np.arange(G))
+    w = _lib.rng_state_words(np.random.default_rng(0))
+    before = ctx.permgen_stats()
+    one = ctx.moran_seeded(w, P)
+    par, seq, fallbacks = (a - b for a, b in zip(ctx.permgen_stats()[:3], before[:3]))
+    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 32
+    wh = _lib.rng_state_words(np.random.default_rng(0))
+    table = _lib.perm_numpy_host(wh, N, P)
+    np.testing.assert_array_equal(w, wh)                                # generator state after 1000 x 1M steps
+    ctx.set_permutations(table)
+    two = ctx.moran(P)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    np.testing.assert_array_equal(one["count_ge"], (one["sims"] >= one["I"]).sum(axis=0))
+    g = csr_matrix((np.full(N * K, 1.0 / K), nbr.reshape(-1), np.arange(0, N * K + 1, K)), shape=(N, N))
+    g.sort_indices()
+    vals = np.ascontiguousarray(X[:, [0, 63]].T, dtype=np.float64)
+    rows = [0, 517, P - 1]
+    np.testing.assert_allclose(one["I"][[0, 63]], oracle.morans_i_scores(g, vals), rtol=1e-9)
+    np.testing.assert_allclose(one["sims"][rows][:, [0, 63]], oracle.morans_i_sims_gather(g, vals, table[rows]),
+                               rtol=1e-9, atol=1e-13)
+
+
 def test_config3_shape_radius_graph_and_lee_pairs(big, oracle):
     """BASELINE configs[2] shape: 1M cells, radius graph r = 30 um, Lee's L for 100 x 100 gene pairs
     (observed statistic; the reference has no radius option for Lee, so this is the kernel-level path)."""

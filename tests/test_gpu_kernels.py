@@ -256,6 +256,65 @@ def test_moran_seeded_pipeline_equals_two_step(ctx, oracle, n, G, P):
     assert_counts_match(one["count_ge"], tab["sims"], tab["I"])
 
 
+@pytest.mark.parametrize("n,G,seed", [(5000, 70, 0), (4096, 33, 9)])
+def test_moran_seeded_bench_schedule_p1000_vs_oracle(ctx, oracle, n, G, seed):
+    """The exact schedule bench.py runs: P = 1000 > 3 chunks switches sc_moran_seeded to the short-first /
+    128 x 7 / short-last chunk bounds, and G = 70 / 33 leaves an odd 16-gene tile count for the 32-gene kernel.
+    Every permutation's statistic, the counts and the final generator state against the oracle."""
+    from spatialcore_amd._lib import rng_state_words
+
+    P, k = 1000, 15
+    coords, X = synth(n, G, 101 + seed, dtype=np.float32)
+    tab = oracle.morans_i_reference_table(coords, X, list(range(G)), k, P, seed=seed)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    ctx.set_expression(X, np.arange(G))
+    w = rng_state_words(np.random.default_rng(seed))
+    before = ctx.permgen_stats()
+    out = ctx.moran_seeded(w, P)
+    assert ctx.moran_source_bits() == 32
+    assert ctx.permgen_stats()[2] == before[2]                         # no silent verification fallback
+    np.testing.assert_array_equal(w, oracle.perm_table(seed, n, P)[1])  # generator state after P permutations
+    np.testing.assert_allclose(out["I"], tab["I"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(out["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
+    assert_counts_match(out["count_ge"], tab["sims"], tab["I"])
+    np.testing.assert_array_equal(out["count_ge"], (out["sims"] >= out["I"]).sum(axis=0))
+    np.testing.assert_allclose(out["sim_sum"], tab["sims"].sum(axis=0), rtol=1e-9, atol=1e-11)
+
+
+def test_moran_seeded_bench_schedule_block_parallel_generator(ctx, oracle):
+    """Same schedule with n >= 131072: the block-parallel exact scan, the CU-masked scoring stream and the
+    inverse-only swap tables all take part (as at 1M cells).  Bit-equal to the two-step path fed with the ORACLE
+    generator's table; three genes against the oracle over all 1000 permutations."""
+    from spatialcore_amd._lib import perm_numpy_host, rng_state_words
+
+    n, G, P, k = 140001, 33, 1000, 15
+    coords, X = synth(n, G, 77, dtype=np.float32, sparse_x=False)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    ctx.set_expression(X, np.arange(G))
+    w = rng_state_words(np.random.default_rng(4))
+    before = ctx.permgen_stats()
+    one = ctx.moran_seeded(w, P)
+    par, seq, fallbacks = (a - b for a, b in zip(ctx.permgen_stats()[:3], before[:3]))
+    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 32
+    # the oracle's own generator (scalar C model of numpy's stream) supplies the table of the two-step run
+    cols = [0, 17, 32]
+    conn = csr_matrix((np.ones(n * k), oracle.knn_tree(coords, k).reshape(-1), np.arange(0, n * k + 1, k)), shape=(n, n))
+    tab = oracle.morans_i_reference_table(coords, X, cols, k, P, seed=4, graph=conn)
+    ctx.set_permutations(tab["perms"])
+    two = ctx.moran(P)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    wh = rng_state_words(np.random.default_rng(4))
+    last = perm_numpy_host(wh, n, P)[P - 1]                  # host generator: last row + state after P permutations
+    np.testing.assert_array_equal(last, tab["perms"][P - 1])
+    np.testing.assert_array_equal(w, wh)
+    np.testing.assert_allclose(one["I"][cols], tab["I"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(one["sims"][:, cols], tab["sims"], rtol=1e-9, atol=1e-13)
+    assert_counts_match(one["count_ge"][cols], tab["sims"], tab["I"])
+
+
 def test_moran_seeded_inverse_only_tables(ctx, oracle):
     """n >= 65536 with a float32 matrix: the pipeline never builds the permutation table, only its inverse (the same
     Fisher-Yates transpositions applied in ascending order).  Scores must equal the two-step path bit for bit, and
@@ -352,6 +411,24 @@ def test_moran_zero_variance_gene_is_nan(ctx, oracle):
     ctx.graph_from_knn(1.0 / 6)
     ctx.set_expression(X, [0, 1, 2])
     ctx.set_permutations(oracle.perm_table(0, 1000, 5)[0])
+    out = ctx.moran(5)
+    assert np.isnan(out["I"][1]) and out["count_ge"][1] == 0
+    assert np.isfinite(out["I"][[0, 2]]).all()
+
+
+@pytest.mark.parametrize("n", [501, 561, 927, 1000])
+def test_constant_gene_is_zero_variance_for_any_cell_count(ctx, oracle, n):
+    """mean = sum / n, not sum * (1/n): for ~10-15 % of the cell counts (49, 98, 103, 107, 501, 561, 927, ...)
+    c * n * fl(1/n) != c, which would leave a constant gene with z = +-1e-16 and a finite I."""
+    assert (float(n) * (1.0 / n) != 1.0) == (n != 1000)                 # three counts that used to fail + one that did not
+    coords, X = synth(n, 3, 4, sparse_x=False)
+    X[:, 1] = 1.0
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, [0, 1, 2])
+    mean, var = ctx.expr_stats()
+    assert mean[1] == 1.0 and var[1] == 0.0
+    ctx.set_permutations(oracle.perm_table(0, n, 5)[0])
     out = ctx.moran(5)
     assert np.isnan(out["I"][1]) and out["count_ge"][1] == 0
     assert np.isfinite(out["I"][[0, 2]]).all()
