@@ -6,13 +6,20 @@
 One step = one full pass of the hot path over one batch of synthetic input that is already
 resident (coordinates on the host as the API takes them, expression tiles in HBM): exact kNN build,
 row-normalised graph, numpy-exact permutation table for `seed`, lag, the permutation kernel for all
-genes, p-value assembly, and (N > 1) one RCCL all-gather of the per-gene results.  Nothing is cached
-between steps.  Workload at every N: BASELINE.json configs[1] per GPU (1M cells, 500 genes, k=15,
-P=1000) -- genes shard across ranks with no data-path collective, so scaling is "weak"
-(total genes = 500 * N).
+genes, p-value assembly, and (N > 1) ONE RCCL all-gather of the per-gene results.  Nothing is cached
+between steps.
 
-torch is used only as plumbing for the multi-process launch contract (process group, barrier,
-all-gather over RCCL); the product itself (spatialcore_amd) does not import it.
+Workloads
+  default          BASELINE.json configs[1] per GPU (1M cells, 500 genes, k=15, P=1000); genes shard across
+                   ranks with no data-path collective, so scaling is "weak" (total genes = 500 * N).
+  --config 3       BASELINE.json configs[3]: 5M cells, 2000 genes IN TOTAL sharded over the N ranks
+                   ("strong" scaling), processed on each rank in batches of <= --gene-batch genes that reuse the
+                   rank's resident permutation table.
+
+No PyTorch: ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the launcher's environment; barrier,
+slowest-rank clock and the final all-gather go through the library's own RCCL communicator
+(spatialcore_amd.parallel.connect -> sc_comm_create / sc_allgather / sc_allreduce_max); the device fence is
+hipDeviceSynchronize (sc_ctx_sync), which is what torch.cuda.synchronize() would call.
 """
 
 from __future__ import annotations
@@ -52,36 +59,98 @@ def synth_inputs(n_cells: int, n_genes: int, seed: int, gene_offset: int = 0):
     return coords, X
 
 
-def cpu_baseline(coords, X, k: int, n_perm_full: int, seed: int, budget_s: float = 20.0):
-    """The oracle's C port of the reference-faithful form (permute the graph rows and redo the CSR
-    sweep, as squidpy -> scanpy do for AC:576-583), one thread, on a bounded sample of the same
-    workload: 8 genes x as many permutations as fit the budget; scaled linearly to P permutations."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as orc  # test infrastructure: CPU baseline leg only
+    import oracle as orc  # test infrastructure: CPU baseline + verification legs only, after the timed region
 
     orc.build_c()
+    return orc
+
+
+def cpu_baseline_and_verify(coords, X, k: int, n_perm_full: int, seed: int, gpu_res: dict, check_genes):
+    """(a) CPU baseline: the oracle's C port of the path on the box's host cores, on a bounded sample of the same
+    workload, in both forms -- the reference-faithful one (permute the graph rows and redo the CSR sweep, as
+    squidpy -> scanpy do behind AC:576-583) and the gather form -- single-threaded (the reference passes n_jobs=1,
+    AC:580) and with OpenMP over genes (scanpy's kernel is @njit(parallel=True), prange over genes).
+    (b) Verification of the timed GPU result: observed I and the count #{sims >= I} over all P permutations for
+    `check_genes`, recomputed by the oracle from its own kNN graph and its own numpy-exact permutation table."""
+    orc = _oracle()
     n = coords.shape[0]
-    genes = min(8, X.shape[1])
+    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("SC_CPU_THREADS", 32))))
     t0 = time.perf_counter()
     g = orc.row_normalize_l1(orc.csr_matrix((np.ones(n * k), orc.knn_tree(coords, k).reshape(-1),
                                              np.arange(0, n * k + 1, k)), shape=(n, n)))
     t_graph = time.perf_counter() - t0
-    vals = np.ascontiguousarray(X[:, :genes].T, dtype=np.float64)
-    t0 = time.perf_counter()
-    orc.morans_i_scores(g, vals)
-    t_obs = time.perf_counter() - t0
-    n_perm = int(max(2, min(n_perm_full, budget_s / max(t_obs, 1e-3))))
-    t0 = time.perf_counter()
-    perms, _ = orc.perm_table(seed, n, n_perm)
-    for p in range(n_perm):
-        orc.morans_i_scores(g, vals, perms[p])
-    t_perm = time.perf_counter() - t0
-    per_gene_s = (t_obs + t_perm * n_perm_full / n_perm) / genes
-    return {"value": 1.0 / per_gene_s, "unit": "genes/s", "cores": 1, "kind": "port",
-            "sample": f"{genes} genes x {n_perm} of {n_perm_full} permutations at {n} cells, k={k}, "
-                      f"row-permuted CSR sweep (scalar C port of the squidpy/scanpy form), scaled linearly; "
-                      f"kNN graph build by cKDTree took {t_graph:.1f}s and is not included",
-            "host_cpus": os.cpu_count()}
+    perms, _ = orc.perm_table(seed, n, n_perm_full)
+
+    def timed_forms(genes: int, nthreads: int, budget_s: float):
+        used = orc.set_threads(nthreads)
+        vals = np.ascontiguousarray(X[:, :genes].T, dtype=np.float64)
+        t0 = time.perf_counter()
+        orc.morans_i_scores(g, vals)                        # observed statistic = one sweep
+        t_obs = time.perf_counter() - t0
+        p_row = int(max(2, min(n_perm_full, (budget_s / 2) / max(t_obs, 1e-3))))
+        t0 = time.perf_counter()
+        for p in range(p_row):
+            orc.morans_i_scores(g, vals, perms[p])
+        t_row = (time.perf_counter() - t0) / p_row
+        p_gat = int(min(n_perm_full, max(8, 16 * p_row)))
+        t0 = time.perf_counter()
+        orc.morans_i_sims_gather(g, vals, perms[:p_gat])    # includes z / lag / scale set-up (one sweep)
+        t_gat = (time.perf_counter() - t0) / p_gat
+        rate_row = genes / (t_obs + t_row * n_perm_full)
+        rate_gat = genes / (t_obs + t_gat * n_perm_full)
+        return used, rate_row, rate_gat, f"{genes} genes x {p_row} (row-permuted) / {p_gat} (gather) of {n_perm_full} permutations"
+
+    g_mt = int(min(X.shape[1], max(8, threads)))
+    used_mt, row_mt, gat_mt, s_mt = timed_forms(g_mt, threads, 10.0)
+    _, row_1, gat_1, s_1 = timed_forms(min(8, X.shape[1]), 1, 10.0)
+    orc.set_threads(threads)
+    base = {"value": row_mt, "unit": "genes/s", "cores": used_mt, "kind": "port",
+            "sample": f"{s_mt} at {n} cells, k={k}, reference-faithful row-permuted CSR sweep (C port of the "
+                      f"squidpy/scanpy form), OpenMP over genes on {used_mt} threads, scaled linearly in permutations; "
+                      f"kNN graph by cKDTree took {t_graph:.1f}s and is not included",
+            "host_cpus": os.cpu_count(), "threads_available": len(os.sched_getaffinity(0)),
+            "forms_genes_per_s": {"row_permuted_1_thread": row_1, f"row_permuted_{used_mt}_threads": row_mt,
+                                  "gather_1_thread": gat_1, f"gather_{used_mt}_threads": gat_mt},
+            "sample_1_thread": s_1}
+
+    # ---- verification of the timed GPU result (2 genes, all P permutations) ----
+    cols = list(check_genes)
+    vals = np.ascontiguousarray(X[:, cols].T, dtype=np.float64)
+    I_ref = orc.morans_i_scores(g, vals)
+    sims = orc.morans_i_sims_gather(g, vals, perms)
+    want = (sims >= I_ref).sum(axis=0)
+    ties = (np.abs(sims - I_ref) <= 1e-11 * np.abs(I_ref)).sum(axis=0)
+    I_gpu, c_gpu = gpu_res["I"][cols], gpu_res["count_ge"][cols]
+    rel = float(np.max(np.abs(I_gpu - I_ref) / np.abs(I_ref)))
+    ok = bool(rel <= 1e-9 and (np.abs(c_gpu - want) <= ties).all())
+    verify = {"verified": ok, "genes_checked": cols, "max_rel_err_I": rel,
+              "count_ge_gpu": [int(v) for v in c_gpu], "count_ge_oracle": [int(v) for v in want],
+              "exact_ties": [int(v) for v in ties],
+              "method": "oracle (cKDTree graph, scalar C numpy-stream model, gather-dot) over all permutations"}
+    return base, verify
+
+
+def public_api_rate(coords, X, k: int, P: int, seed: int, device: int):
+    """G / wall time of morans_i(adata, genes=all, n_neighbors=k, n_permutations=P, seed=seed) on a float32 CSR
+    AnnData: everything the user's call pays (validation, PCIe upload of the matrix, graph, obsp side effects,
+    DataFrame) -- SURVEY 8(d)'s definition of the metric.  Second of two calls (the first also pays hipMalloc)."""
+    import pandas as pd
+    from scipy import sparse
+
+    from spatialcore_amd import SimpleAnnData
+    from spatialcore_amd.spatial import morans_i
+
+    Xs = sparse.csr_matrix(X)
+    ad = SimpleAnnData(Xs, obs=pd.DataFrame(index=pd.RangeIndex(X.shape[0]).astype(str)),
+                       var_names=[f"g{i}" for i in range(X.shape[1])], obsm={"spatial": coords})
+    walls = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        morans_i(ad, genes=list(ad.var_names), n_neighbors=k, n_permutations=P, seed=seed, device=device)
+        walls.append(time.perf_counter() - t0)
+    return X.shape[1] / walls[1], walls, ad.uns["morans_i"]
 
 
 def main() -> None:
@@ -89,114 +158,158 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=1_000_000)
-    ap.add_argument("--genes", type=int, default=500, help="genes per GPU")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3),
+                    help="BASELINE.json configs index: 1 = 1M cells x 500 genes per GPU (weak scaling, the metric); "
+                         "3 = 5M cells x 2000 genes in total (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
+    ap.add_argument("--cells", type=int, default=None)
+    ap.add_argument("--genes", type=int, default=None, help="genes per GPU (weak) / in total (strong)")
+    ap.add_argument("--gene-batch", type=int, default=256, help="strong mode: genes resident per batch")
     ap.add_argument("--perms", type=int, default=1000)
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline + oracle verification leg")
+    ap.add_argument("--no-public-api", action="store_true")
     ap.add_argument("--source-bits", type=int, default=32, choices=(32, 64),
                     help="narrowest exact copy of the expression values the permutation kernel may gather "
                          "(32: float32 raw values, 64: the general fp64 kernel)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="testing only: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code path "
-                         "on a 1-GPU box; never a measurement)")
+                    help="testing only: all ranks share GPU 0 and exchange through files (RCCL refuses duplicate "
+                         "devices); exercises the N > 1 code path on a 1-GPU box; never a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-
-    import torch
-    import torch.distributed as dist
-
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N ...)")
     rehearse = args.rehearse_on_one_gpu
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if rehearse:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = "cpu" if rehearse else "cuda"
 
-    from spatialcore_amd import _lib
+    from spatialcore_amd import _lib, parallel
     from spatialcore_amd.spatial.autocorrelation import _moran_resident
 
-    n, G, P, k = args.cells, args.genes, args.perms, args.k
-    coords, X = synth_inputs(n, G, seed=42, gene_offset=rank * G)
+    strong = (args.scaling or ("strong" if args.config == 3 else "weak")) == "strong"
+    n = args.cells or (5_000_000 if args.config == 3 else 1_000_000)
+    genes_arg = args.genes or (2000 if args.config == 3 else 500)
+    P, k = args.perms, args.k
+    if strong:
+        g_lo, g_hi = parallel.shard_bounds(genes_arg, world, rank)
+        G_total, G_mine = genes_arg, g_hi - g_lo
+    else:
+        g_lo, G_total, G_mine = rank * genes_arg, genes_arg * world, genes_arg
+
     ctx = _lib.Context(local_rank)
+    comm = parallel.connect(ctx, transport="file" if rehearse else None)
     ctx.set_moran_source_bits(args.source_bits)
-    ctx.set_expression(X, np.arange(G))   # inputs resident in HBM before the timed region
+
+    # ---- synthetic inputs; resident in HBM before the timed region (weak mode: the rank's whole matrix) ----
+    batch = min(args.gene_batch, max(G_mine, 1)) if strong else G_mine
+    coords, X = synth_inputs(n, batch, seed=42, gene_offset=g_lo)
+    batches = [(b, min(b + batch, G_mine)) for b in range(0, G_mine, batch)]
+    if len(batches) == 1:
+        ctx.set_expression(X, np.arange(X.shape[1]))
+
+    def batch_matrix(bi: int):
+        # strong mode, later batches: the base block rolled along the cells (new values per gene at no RNG cost;
+        # the timing does not depend on the values)
+        return X if bi == 0 else np.roll(X, 7919 * bi, axis=0)
 
     gathered = None
+    mem_peak = 0
+
+    import contextlib
+
+    # rehearsal only: the ranks share ONE GPU and take turns on it (parallel.device_turn explains why)
+    turn = parallel.device_turn if rehearse else contextlib.nullcontext
 
     def step():
         nonlocal gathered
-        ctx.knn(coords, k, fetch=False)
-        ctx.graph_from_knn(1.0 / k)
-        res = _moran_resident(ctx, n, P, args.seed)
+        with turn():
+            res, mine = device_part()
+            if rehearse:
+                ctx.sync()
         if world > 1:
-            mine = torch.from_numpy(np.stack([res["I"], res["p_value"]])).to(dev)
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)           # the single RCCL collective: per-gene I and p
-            gathered = torch.stack(parts).cpu().numpy()
+            gathered = parallel.all_gather_rows(mine, G_total, comm) if strong else comm.all_gather(mine)
         return res
 
+    def device_part():
+        nonlocal mem_peak
+        ctx.knn(coords, k, fetch=False)
+        ctx.graph_from_knn(1.0 / k)
+        rows = []
+        res = None
+        for bi, (b0, b1) in enumerate(batches):
+            if len(batches) > 1:
+                ctx.set_expression(batch_matrix(bi)[:, : b1 - b0], np.arange(b1 - b0))   # upload inside the step
+            if bi == 0:
+                res = _moran_resident(ctx, n, P, args.seed)                # generator + scoring, pipelined
+            else:
+                res = _moran_resident(ctx, n, P, args.seed, reuse_table=True)   # the rank's resident table
+            rows.append(np.stack([res["I"], res["p_value"]], axis=1))
+        mem_peak = max(mem_peak, ctx.device_mem())
+        mine = np.concatenate(rows, axis=0) if rows else np.zeros((0, 2))
+        return res, mine
+
     def fence():
-        if world > 1:
-            dist.barrier()
-        ctx.sync()
-        torch.cuda.synchronize()
+        comm.barrier()          # an RCCL all-reduce at N > 1
+        ctx.sync()              # hipDeviceSynchronize
 
     for _ in range(args.warmup):
         step()
     fence()
     ctx.reset_timers()
+    pg0 = ctx.permgen_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(comm.max_over_ranks([time.perf_counter() - t0])[0])
+    pg = tuple(a - b for a, b in zip(ctx.permgen_stats(), pg0))
 
     perm_ms, perm_launches = ctx.kernel_time(_lib.K_MORAN_PERM)
     lag_ms, _ = ctx.kernel_time(_lib.K_LAG)
     scan_ms, _ = ctx.kernel_time(_lib.K_PERM_SCAN)
     swap_ms, _ = ctx.kernel_time(_lib.K_PERM_SWAP)
     knn_ms, _ = ctx.kernel_time(_lib.K_KNN)
+    fallbacks = int(comm.max_over_ranks([float(pg[2])])[0])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = G * world * args.steps / elapsed
-        # algorithmic bytes (SURVEY.md 8(d) streaming model, the contract figure): 16 B per (permutation, gene,
-        # cell) [z + gathered lag, fp64] + 4 B per (permutation, cell) -> per step tiles16 x (P*16*n*16 + P*n*4),
-        # divided by the launches of a step (a launch = one 32-gene tile pair x one chunk of permutations).
-        # The float32-source kernel moves LESS than this model (4-B gathered operand, streamed lag shared through
-        # the caches), so `achieved` can exceed the HBM peak; `traffic` (PMC) is what the launch really fetched
-        # and `hbm_frac_measured` prices that against the peak.
-        tiles = (G + 15) // 16
-        launches_per_step = max(perm_launches // max(args.steps, 1), 1)
-        alg_bytes = tiles * (P * 16 * n * 16.0 + P * n * 4.0) / launches_per_step
-        avg_ms = perm_ms / max(perm_launches, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
-        traffic = None
-        # the synthetic matrix is float32 like an AnnData X: the library gathers the raw float32 values, 32 genes
-        # per row (--source-bits 64 forces the general fp64 kernel)
+        value = G_total * args.steps / elapsed
         source_bits = ctx.moran_source_bits()
         kernel_name = {32: "k_moran_perm32", 64: "k_moran_perm"}[source_bits]
+        genes_per_launch = {32: 32, 64: 16}[source_bits]
+        launches_per_step = max(perm_launches // max(args.steps, 1), 1)
+        avg_ms = perm_ms / max(perm_launches, 1)
+        G_pad = -(-batch // genes_per_launch) * genes_per_launch * len(batches)
+        # (1) what THIS kernel's formulation has to move per step (its algorithmic bytes): one 128-byte row of raw
+        #     values per (permutation, cell, launch tile), one 4-byte index per (permutation, cell, tile), and the
+        #     streamed fp64 lag rows once per launch (16 B x genes_per_launch x cells).
+        tiles = G_pad // genes_per_launch
+        kernel_bytes_step = tiles * (P * n * (128.0 + 4.0)) + launches_per_step * n * 8.0 * genes_per_launch
+        kernel_bytes = kernel_bytes_step / launches_per_step
+        achieved = kernel_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
+        # (2) SURVEY.md 8(d)'s streaming model (the contract's per-unit figure: 16 B per (permutation, gene, cell) for
+        #     fp64 z + gathered fp64 lag, + 4 B per (permutation, cell)) -- an EFFECTIVE rate: the kernel moves fewer
+        #     bytes than the model (float32 32-gene rows, lag shared through the caches), so it can exceed the peak.
+        model_bytes = (P * G_mine * n * 16.0 + P * n * 4.0) / launches_per_step
+        effective = model_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
+        # (3) PMC counters of the same kernel build, collected by scripts/pmc_traffic.py (separate --pmc passes)
+        traffic, traffic_note = None, "no PMC file for this kernel"
         tpath = os.path.join(ROOT, "profiles", f"{kernel_name}_pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("cells") == n and tj.get("perms") == P and tj.get("kernel") == kernel_name:
-                traffic = tj.get("hbm_bytes_per_launch")
+            same = (tj.get("cells") == n and tj.get("perms") == P and tj.get("kernel") == kernel_name
+                    and tj.get("genes_per_gpu") == G_mine)
+            if same and tj.get("source_hash") == _lib.source_hash():
+                traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(tpath)
+            else:
+                traffic_note = ("stale: " + os.path.basename(tpath) + " was measured on another workload or another "
+                                "build of csrc/sc_moran.hip (source_hash mismatch); re-run scripts/pmc_traffic.py")
         line = {
             "metric": "genes/sec Moran's I (1000 perms, 1M cells, k=15)",
             "value": value,
@@ -206,31 +319,56 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL on one GPU over gloo -- not a measurement)",
-            "config": {"workload": f"{n} cells (uniform 2-D), {G} genes per GPU, k={k} kNN, "
-                                   f"{P} numpy-exact permutations, seed={args.seed}"
-                                   + (" (BASELINE configs[1])" if (n, G, P, k) == (1_000_000, 500, 1000, 15) else " (non-default size)"),
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL on one GPU, file transport -- not a measurement)",
+            "config": {"workload": f"{n} cells (uniform 2-D), "
+                                   + (f"{G_total} genes in total sharded over {world} GPU(s) in batches of <= {batch}"
+                                      if strong else f"{G_mine} genes per GPU")
+                                   + f", k={k} kNN, {P} numpy-exact permutations, seed={args.seed}"
+                                   + (" (BASELINE configs[1])" if (n, genes_arg, P, k, strong) == (1_000_000, 500, 1000, 15, False)
+                                      else " (BASELINE configs[3])" if (n, genes_arg, P, k, strong) == (5_000_000, 2000, 1000, 15, True)
+                                      else " (non-default size)"),
                        "expression_source": {32: "float32", 64: "float64"}[source_bits],
-                       "cells": n, "genes_per_gpu": G, "genes_total": G * world, "k": k, "perms": P,
-                       "parallelism": f"gene-shard x{world}, one all-gather of (I, p)"},
+                       "cells": n, "genes_per_gpu": G_mine, "genes_total": G_total, "k": k, "perms": P,
+                       "parallelism": f"gene-shard x{world}, one RCCL all-gather of (I, p)"
+                                      + (" [file transport, rehearsal]" if rehearse else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and perm_launches else None,
                          "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": perm_launches,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": kernel_bytes,
+                         "basis": "bytes this kernel's formulation must move (128-B raw-value row + 4-B index per "
+                                  "(permutation, cell, tile), lag rows once per launch) / HIP-event launch time",
+                         "effective": effective, "effective_frac": effective / HBM_PEAK_GBS,
+                         "effective_basis": "SURVEY 8(d) streaming model, 16 B per (permutation, gene, cell) + 4 B per "
+                                            "(permutation, cell); may exceed the peak, the kernel moves fewer bytes",
+                         "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and perm_launches else None,
+                         "traffic_source": traffic_note},
             "breakdown_ms_per_step": {"perm_scan_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
                                       "moran_perm_kernel": perm_ms / args.steps,
                                       "lag_kernel": lag_ms / args.steps, "knn_kernel": knn_ms / args.steps},
+            "permgen_stats": {"jobs_block_parallel": pg[0], "jobs_sequential": pg[1],
+                              "verification_fallbacks_max_over_ranks": fallbacks,
+                              "blocks_prepared": pg[3], "blocks_chain": pg[4]},
+            "device_mem_bytes_rank0": mem_peak,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(coords, X, k, P, args.seed)
+        if fallbacks:
+            line["warning"] = "the block-parallel generator fell back to the sequential scan inside the timed region"
+        if world == 1 and not strong and not args.no_public_api:
+            rate, walls, _ = public_api_rate(coords, X, k, P, args.seed, local_rank)
+            line["value_public_api"] = rate
+            line["public_api"] = {"call": f"morans_i(adata, genes=all {X.shape[1]}, n_neighbors={k}, n_permutations={P}, "
+                                          f"seed={args.seed}) on a float32 CSR AnnData, host arrays in, DataFrame out",
+                                  "wall_s_first_call": walls[0], "wall_s": walls[1]}
+        if world == 1 and not strong and not args.no_cpu_baseline:
+            base, verify = cpu_baseline_and_verify(coords, X, k, P, args.seed, res, (0, X.shape[1] - 1))
+            line["cpu_baseline"] = base
+            line["verified"] = verify["verified"] and fallbacks == 0
+            line["verification"] = verify
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
     ctx.close()
 
 

@@ -55,6 +55,11 @@ def clib() -> ctypes.CDLL:
     return _LIB
 
 
+def set_threads(n: int) -> int:
+    """OpenMP threads of the two Moran kernels (genes in parallel, as scanpy's prange); returns the count in effect."""
+    return int(clib().orc_set_threads(ctypes.c_int(int(n))))
+
+
 def _p(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
 

@@ -29,6 +29,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef unsigned __int128 u128;
 
@@ -128,6 +131,18 @@ int orc_raw_uint32(uint64_t *st, int64_t n32, uint32_t *out)
     return 0;
 }
 
+/* threads used by the two Moran kernels below (results do not depend on it); returns the count in effect */
+int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* lag[i] = sum_j data[j]*z[indices[j]] over row i, sequential fp64 (scanpy _morans_i_vec_W inner loop). */
 void orc_csr_lag(const int64_t *indptr, const int32_t *indices, const double *data,
                  int64_t n, const double *z, double *lag)
@@ -150,7 +165,12 @@ void orc_moran_rowperm(const int64_t *indptr, const int32_t *indices, const doub
 {
     double W = 0.0;
     for (int64_t e = 0; e < indptr[n]; ++e) W += data[e];
+    /* genes in parallel, one gene's arithmetic strictly sequential -- the shape of scanpy's
+     * @njit(parallel=True) kernel (prange over genes); orc_set_threads(1) gives the n_jobs=1 figure */
+#pragma omp parallel
+    {
     double *z = (double *)malloc(sizeof(double) * (size_t)n);
+#pragma omp for schedule(dynamic, 1)
     for (int64_t g = 0; g < n_genes; ++g) {
         const double *x = vals + g * n;
         double m = 0.0;
@@ -168,15 +188,17 @@ void orc_moran_rowperm(const int64_t *indptr, const int32_t *indices, const doub
         out[g] = (double)n / W * inum / z2;
     }
     free(z);
+    }
 }
 
 /* Gather form: sims[p*G+g] = scale[g] * sum_i z_g[i] * lag_g[perm_p[i]]; z, lag gene-major [G][n]. */
 void orc_gather_dot(const double *z, const double *lag, int64_t n, int64_t n_genes,
                     const int32_t *perm, int64_t n_perm, const double *scale, double *sims)
 {
+#pragma omp parallel for collapse(2) schedule(static)
     for (int64_t p = 0; p < n_perm; ++p) {
-        const int32_t *pi = perm + p * n;
         for (int64_t g = 0; g < n_genes; ++g) {
+            const int32_t *pi = perm + p * n;
             const double *zg = z + g * n, *lg = lag + g * n;
             double s = 0.0;
             for (int64_t i = 0; i < n; ++i) s += zg[i] * lg[pi[i]];

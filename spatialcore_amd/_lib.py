@@ -37,6 +37,7 @@ SYMBOLS = {
     "sc_ctx_moran_source_bits": [_P, _P],
     "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
+    "sc_debug_copy": [_P, c_int, c_int64, _P, c_int64],
     "sc_knn_2d": [_P, _P, c_int64, c_int, c_int, _P, _P],
     "sc_radius_count_2d": [_P, _P, c_int64, c_double, _P],
     "sc_radius_fill_2d": [_P, c_int64, _P],
@@ -97,6 +98,19 @@ def load_library() -> ctypes.CDLL:
             lib.sc_last_error.restype = c_char_p
             _lib = lib
     return _lib
+
+
+def source_hash(names=("sc_moran.hip", "sc_ctx.h")) -> str:
+    """sha256 over the native sources that hold the scoring kernels: ties a measured artefact
+    (profiles/*_pmc_traffic.json) to the kernel code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in names:
+        h.update(name.encode())
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _check(rc: int) -> None:
@@ -211,6 +225,11 @@ class Context:
         v = [c_int64(0) for _ in range(5)]
         _check(self._lib.sc_ctx_permgen_stats(self._h, *[byref(x) for x in v]))
         return tuple(x.value for x in v)
+
+    def debug_copy(self, which: int, offset_bytes: int, count: int, dtype) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _check(self._lib.sc_debug_copy(self._h, int(which), int(offset_bytes), _ptr(out), out.nbytes))
+        return out
 
     def device_mem(self) -> int:
         v = c_int64(0)

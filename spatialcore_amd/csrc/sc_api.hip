@@ -184,7 +184,22 @@ int sc_ctx_destroy(sc_ctx *c)
 int sc_ctx_sync(sc_ctx *c)
 {
     SC_REQUIRE(c, SC_ERR_INVALID, "null context");
-    SC_HIP(hipStreamSynchronize(c->stream));
+    SC_HIP(hipSetDevice(c->device));
+    SC_HIP(hipDeviceSynchronize());  // every stream of the device (what torch.cuda.synchronize() would do)
+    return SC_OK;
+}
+
+// Development aid: copy `bytes` bytes at `offset` of one of the generator's device buffers to the host.
+int sc_debug_copy(sc_ctx *c, int which, int64_t offset, void *out, int64_t bytes)
+{
+    SC_REQUIRE(c && out && offset >= 0 && bytes >= 0, SC_ERR_INVALID, "sc_debug_copy: bad argument");
+    SC_HIP(hipSetDevice(c->device));
+    const DBuf *bufs[] = {&c->pg_J, &c->pg_raw, &c->pg_bits, &c->pg_enter, &c->pg_sblk, &c->pg_out, &c->perm, &c->inv};
+    SC_REQUIRE(which >= 0 && which < (int)(sizeof(bufs) / sizeof(bufs[0])), SC_ERR_INVALID, "sc_debug_copy: unknown buffer %d", which);
+    const DBuf *b = bufs[which];
+    SC_REQUIRE((size_t)(offset + bytes) <= b->cap, SC_ERR_INVALID, "sc_debug_copy: range exceeds the buffer (%zu bytes)", b->cap);
+    SC_HIP(hipDeviceSynchronize());
+    SC_HIP(hipMemcpy(out, (const char *)b->p + offset, (size_t)bytes, hipMemcpyDeviceToHost));
     return SC_OK;
 }
 

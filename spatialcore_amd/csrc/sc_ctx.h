@@ -114,6 +114,7 @@ struct sc_ctx {
     DBuf perm;
     DBuf perm_flag;
     DBuf inv;                      // inverse permutations, same layout as perm (rows valid on demand)
+    int64_t inv_rows_valid = 0;    // leading rows of c->inv known to be the inverses of the active table's rows
     bool perm_forward_valid = true; // c->perm holds the active table (false: only its inverse, c->inv, was generated)
     bool perm_bijective = false;   // the active table is known to hold true permutations
     bool perm_checked = false;     // ... or was checked and is not

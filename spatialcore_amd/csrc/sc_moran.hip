@@ -6,6 +6,7 @@
 // 128-byte row.  The permutation table is [perm][cell] int32 with a row stride that is a multiple
 // of 32 elements so that rows can be read as int4.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -725,18 +726,20 @@ static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
 {
     *bits = 64;
     if (n_perm <= 0 || moran_source_bits(c) == 64) return SC_OK;
-    SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
+    const int64_t rows = c->p_count > n_perm ? c->p_count : n_perm;  // the WHOLE table is checked once
+    SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * rows + 32), &c->mem));
     if (!c->perm_bijective && !c->perm_checked) {
-        SC_TRY(invert_rows(c, 0, n_perm, c->stream));
+        SC_TRY(invert_rows(c, 0, rows, c->stream));
         SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
         SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_check_inverse, dim3(2048), dim3(256), 0, c->stream, c->perm.as<int32_t>(),
-                           c->inv.as<int32_t>(), c->e_n, c->p_stride, n_perm, c->perm_flag.as<int>());
+                           c->inv.as<int32_t>(), c->e_n, c->p_stride, rows, c->perm_flag.as<int>());
         int bad = 0;
         SC_HIP(hipMemcpyAsync(&bad, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         SC_HIP(hipStreamSynchronize(c->stream));
         c->perm_checked = true;
         c->perm_bijective = (bad == 0);
+        if (c->perm_bijective) c->inv_rows_valid = rows;
     }
     if (c->perm_bijective) *bits = moran_source_bits(c);
     return SC_OK;
@@ -828,7 +831,6 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
                         double *sim_sum_out, double *sim_sumsq_out)
 {
     SC_TRY(moran_check(c, n_perm, I_out));
-    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
     if (n_perm > 0) {
         SC_REQUIRE(c->p_count >= n_perm, SC_ERR_STATE, "sc_moran: permutation table holds %lld rows, need %lld",
                    (long long)c->p_count, (long long)n_perm);
@@ -838,10 +840,19 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1),
                           &c->mem));
+    // A table left by sc_moran_seeded may exist only as inverse rows, which is all the float32-source kernel reads:
+    // the permutation rows themselves are materialised only when something needs them (the fp64 kernel, or rows
+    // whose inverse is not there yet).
+    const bool inverse_suffices = n_perm > 0 && c->perm_bijective && c->inv_rows_valid >= n_perm &&
+                                  moran_source_bits(c) == 32;
+    if (n_perm > 0 && !inverse_suffices) SC_TRY(sc_perm_forward_ensure(c));
     int bits = 64;
     SC_TRY(moran_choose_path(c, n_perm, &bits));
-    for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK)
-        SC_TRY(moran_perm_range(c, p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm, bits, true));
+    for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) {
+        const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
+        SC_TRY(moran_perm_range(c, p0, p1, bits, p1 > c->inv_rows_valid));
+        if (bits == 32 && p1 > c->inv_rows_valid) c->inv_rows_valid = p1;
+    }
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
@@ -868,7 +879,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     SC_TRY(sc_perm_alloc(c, n, n_perm));
     if (!c->stream2) {  // the generator chain is the critical path: highest priority (plain stream if refused)
         int prio_lo = 0, prio_hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+        if (getenv("SC_NO_STREAM_PRIORITY") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
             (void)hipGetLastError();
             c->stream2 = nullptr;
@@ -959,6 +970,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     if (rc != SC_OK) return rc;
     SC_TRY(permgen_finish(c, &job, state6));
     c->p_count = n_perm;
+    c->inv_rows_valid = n_perm;  // every chunk left its inverse rows (ascending swaps, or k_invert_perm)
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 

@@ -133,6 +133,7 @@ int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
     c->perm_bijective = false;
     c->perm_checked = false;
     c->perm_forward_valid = true;
+    c->inv_rows_valid = 0;
     return SC_OK;
 }
 

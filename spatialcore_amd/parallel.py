@@ -119,10 +119,41 @@ class FileComm:
         self.all_gather(np.zeros(1))
 
     def close(self) -> None:
-        try:
-            os.unlink(self._name(self._round - 1, self.rank))
-        except OSError:
-            pass
+        """A rank is done once its last all_gather has returned, i.e. it has read everything it will ever read;
+        rank 0 waits for every rank's marker and then removes the directory."""
+        import shutil
+
+        _publish(os.path.join(self._dir, f"done_{self.rank}"), b"")
+        if self.rank == 0:
+            for r in range(self.world):
+                _await_file(os.path.join(self._dir, f"done_{r}"), self._timeout)
+            shutil.rmtree(self._dir, ignore_errors=True)
+
+
+class device_turn:
+    """``with device_turn(path):`` -- ranks that SHARE one GPU in a rehearsal take turns on it (an exclusive file
+    lock).  Two processes running kernels on one MI355X at the same time were measured to corrupt in-flight wave
+    state now and then (profiles/r02_gpu_sharing_raw_stream_corruption.txt); with one process per GPU -- the
+    deployment model -- nothing is shared and this is never used."""
+
+    def __init__(self, path: Optional[str] = None):
+        self._path = path or (rendezvous_file(0) + ".turn")
+        self._fd = None
+
+    def __enter__(self):
+        import fcntl
+
+        self._fd = os.open(self._path, os.O_CREAT | os.O_RDWR, 0o600)
+        fcntl.flock(self._fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self._fd, fcntl.LOCK_UN)
+        os.close(self._fd)
+        self._fd = None
+        return False
 
 
 class _SoloComm:
@@ -141,7 +172,7 @@ class _SoloComm:
         pass
 
 
-def connect(ctx=None, transport: Optional[str] = None, timeout_s: float = 300.0):
+def connect(ctx=None, transport: Optional[str] = None, timeout_s: Optional[float] = None):
     """Communicator of this rank among ``WORLD_SIZE`` ranks.
 
     ``transport``: ``"rccl"`` (default; needs ``ctx``, the rank's ``_lib.Context`` on its own GPU) or
@@ -151,6 +182,8 @@ def connect(ctx=None, transport: Optional[str] = None, timeout_s: float = 300.0)
     rank, world, _ = world_info()
     if world == 1:
         return _SoloComm()
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SC_COMM_TIMEOUT_S", 300.0))
     transport = transport or os.environ.get("SC_COMM_TRANSPORT", "rccl")
     seq, _connects = _connects, _connects + 1
     path = rendezvous_file(seq)

@@ -209,11 +209,15 @@ def _norm_sf_cdf(z: np.ndarray) -> np.ndarray:
     return p
 
 
-def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int) -> dict:
+def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_table: bool = False) -> dict:
     """Global Moran's I on operands already resident on the device (graph + expression tiles):
     numpy-exact permutation table -> lag / permutation kernels -> p-value assembly as squidpy's
-    ``_p_value_calc`` / ``_analytic_pval`` do [upstream].  Shared by ``morans_i`` and ``bench.py``."""
-    if n_permutations > 0:
+    ``_p_value_calc`` / ``_analytic_pval`` do [upstream].  Shared by ``morans_i`` and ``bench.py``.
+    ``reuse_table``: score against the permutation table an earlier call with the same seed left on the device
+    (gene batches of one ``morans_i`` call share the table, as squidpy's permutations are shared by all genes)."""
+    if n_permutations > 0 and reuse_table:
+        out = ctx.moran(n_permutations, return_sims=False)
+    elif n_permutations > 0:
         # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1.  Table generation and
         # scoring are pipelined on the device (sc_moran_seeded).
         words = _lib.rng_state_words(np.random.default_rng(seed))
@@ -232,6 +236,7 @@ def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int) -> dict:
         large = out["count_ge"].copy()
         flip = (n_permutations - large) < large
         large[flip] = n_permutations - large[flip]
+        res["count_ge"] = out["count_ge"]
         res["pval_sim"] = res["p_value"] = (large + 1) / (n_permutations + 1)
         mean_sim = out["sim_sum"] / n_permutations
         res["var_sim"] = np.maximum(out["sim_sumsq"] / n_permutations - mean_sim ** 2, 0.0)

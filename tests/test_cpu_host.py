@@ -176,15 +176,13 @@ def test_shard_bounds_cover_everything_once():
         shard_bounds(5, 2, 2)
 
 
-_GLOO_WORKER = r"""
+_WORKER_COMMON = r"""
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
-import numpy as np, pandas as pd, torch.distributed as dist
+import numpy as np, pandas as pd
 import oracle as orc
 from conftest import synth, make_adata
 from spatialcore_amd.parallel import morans_i_sharded, world_info
-dist.init_process_group("gloo")
-rank, world, _ = world_info()
 coords, X = synth(600, 7, 3)
 ad = make_adata(coords, X)
 calls = []
@@ -195,16 +193,47 @@ def cpu_checker(adata, gene_list, n_neighbors=6, n_permutations=10, seed=0):
     t = orc.morans_i_reference_table(coords, X, cols, n_neighbors, n_permutations, seed)
     return pd.DataFrame({{"gene": gene_list, "I": t["I"], "expected_I": t["expected_I"], "z_score": t["z_score"], "p_value": t["p_value"]}})
 genes = [f"g{{i}}" for i in (5, 0, 3, 6, 1, 2, 4)]
-morans_i_sharded(ad, genes=genes, compute=cpu_checker, n_neighbors=6, n_permutations=9, seed=4)
-full = orc.morans_i_reference_table(coords, X, [5, 0, 3, 6, 1, 2, 4], 6, 9, 4)
-df = ad.uns["morans_i"]
-assert list(df["gene"]) == genes
-np.testing.assert_array_equal(df["I"].values, full["I"])
-np.testing.assert_array_equal(df["p_value"].values, full["p_value"])
-np.testing.assert_array_equal(df["z_score"].values, full["z_score"])
-assert len(calls) == 1 and len(calls[0]) == (4 if rank == 0 else 3)
+def check(rank):
+    full = orc.morans_i_reference_table(coords, X, [5, 0, 3, 6, 1, 2, 4], 6, 9, 4)
+    df = ad.uns["morans_i"]
+    assert list(df["gene"]) == genes
+    np.testing.assert_array_equal(df["I"].values, full["I"])
+    np.testing.assert_array_equal(df["p_value"].values, full["p_value"])
+    np.testing.assert_array_equal(df["z_score"].values, full["z_score"])
+    assert len(calls) == 1 and len(calls[0]) == (4 if rank == 0 else 3)
+    open(os.path.join(os.environ["SC_TEST_OUT"], f"ok_{{rank}}"), "w").write("ok")
+"""
+
+_GLOO_WORKER = _WORKER_COMMON + r"""
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+class GlooComm:
+    # torch lives in this TEST only: the product's collective is RCCL through the C ABI (or FileComm for rehearsal)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    def all_gather(self, block):
+        mine = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float64))
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return torch.stack(parts).numpy()
+    def close(self): pass
+rank, world, _ = world_info()
+assert (rank, world) == (dist.get_rank(), 2)
+morans_i_sharded(ad, genes=genes, compute=cpu_checker, comm=GlooComm(), n_neighbors=6, n_permutations=9, seed=4)
+check(rank)
 dist.barrier(); dist.destroy_process_group()
-open(os.path.join(os.environ["SC_TEST_OUT"], f"ok_{{rank}}"), "w").write("ok")
+"""
+
+_FILE_WORKER = _WORKER_COMMON + r"""
+rank, world, _ = world_info()
+# no comm given + a CPU compute: morans_i_sharded opens the file transport itself (and closes it)
+morans_i_sharded(ad, genes=genes, compute=cpu_checker, n_neighbors=6, n_permutations=9, seed=4)
+check(rank)
+from spatialcore_amd.parallel import connect
+c = connect(None, transport="file")
+assert c.max_over_ranks([float(rank), 5.0 - rank]).tolist() == [1.0, 5.0]
+got = c.all_gather(np.full((2, 3), float(rank)))
+assert got.shape == (2, 2, 3) and (got[0] == 0).all() and (got[1] == 1).all()
+c.barrier(); c.close()
 """
 
 
@@ -219,3 +248,35 @@ def test_gene_sharding_world_size_2_gloo(tmp_path, oracle):
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_gene_sharding_world_size_2_file_transport_without_torch(tmp_path, oracle):
+    """The same shard/merge through the product's own rehearsal transport (FileComm), launched as two plain
+    processes with RANK / WORLD_SIZE in the environment: nothing on this path imports torch."""
+    script = tmp_path / "worker.py"
+    script.write_text(_FILE_WORKER.format(root=ROOT) + "\nassert 'torch' not in sys.modules\n")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", OMP_NUM_THREADS="1",
+                   SC_TEST_OUT=str(tmp_path), SC_RENDEZVOUS_FILE=str(tmp_path / "rdv"), SC_COMM_TRANSPORT="file", SC_COMM_TIMEOUT_S="60")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+    assert not list(tmp_path.glob("rdv*"))                      # the transport cleans up after itself
+
+
+def test_rendezvous_name_is_shared_by_siblings_and_overridable(monkeypatch):
+    from spatialcore_amd import parallel
+
+    monkeypatch.delenv("SC_RENDEZVOUS_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    a = parallel.rendezvous_file(0)
+    assert a == parallel.rendezvous_file(0) != parallel.rendezvous_file(1)
+    assert f"_{os.getppid()}_" in a and a.endswith("_29999.0")
+    monkeypatch.setenv("SC_RENDEZVOUS_FILE", "/tmp/x/y")
+    assert parallel.rendezvous_file(3) == "/tmp/x/y.3"
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    solo = parallel.connect()
+    assert solo.world == 1 and solo.all_gather(np.ones(3)).shape == (1, 3)

@@ -1,0 +1,105 @@
+"""GPU: the N > 1 path with the HIP compute.  This file sorts first on purpose: its child processes are started
+before the pytest process itself has touched the GPU.
+
+A 1-GPU box cannot run RCCL between two ranks (RCCL refuses two ranks on one device), so the two-rank runs share
+GPU 0 and exchange their result blocks through the product's rehearsal transport (parallel.FileComm); the RCCL
+communicator itself (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather, ncclAllReduce) is exercised with a
+world of one rank.  The 8-GPU run over xGMI is the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+from conftest import synth, make_adata
+from spatialcore_amd.parallel import device_turn, morans_i_sharded, world_info
+from spatialcore_amd.spatial import morans_i
+assert 'torch' not in sys.modules
+def hip_shard(adata, gene_list, **kw):
+    # the two ranks share ONE GPU here: they take turns on it (see parallel.device_turn); the HIP compute is the product's
+    with device_turn():
+        out = morans_i(adata, genes=gene_list, key_added="_shard", device=0, **kw).uns.pop("_shard")
+        _lib.default_context(0).sync()
+    return out
+from spatialcore_amd import _lib
+rank, world, local_rank = world_info()
+assert world == 2 and local_rank == 0
+coords, X = synth(30000, 45, 3, dtype=np.float32)
+genes = [f"g{{i}}" for i in np.random.default_rng(1).permutation(45)]
+ad = make_adata(coords, X)
+morans_i_sharded(ad, genes=genes, compute=hip_shard, n_neighbors=15, n_permutations=130, seed=4)    # 23 / 22 genes
+whole = make_adata(coords, X)
+with device_turn():
+    morans_i(whole, genes=genes, n_neighbors=15, n_permutations=130, seed=4)
+    _lib.default_context(0).sync()
+a, b = ad.uns["morans_i"], whole.uns["morans_i"]
+assert list(a["gene"]) == genes == list(b["gene"])
+for col in ("I", "expected_I", "z_score", "p_value"):
+    np.testing.assert_array_equal(a[col].values, b[col].values, err_msg=col)       # sharded == unsharded, bit for bit
+assert 'torch' not in sys.modules
+open(os.path.join(os.environ["SC_TEST_OUT"], f"ok_{{rank}}"), "w").write("ok")
+"""
+
+
+def _launch_two(cmd_of_rank, tmp_path, extra_env=None):
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_PORT="29571",
+                   SC_TEST_OUT=str(tmp_path), SC_RENDEZVOUS_FILE=str(tmp_path / "rdv"), SC_COMM_TRANSPORT="file",
+                   SC_COMM_TIMEOUT_S="240", **(extra_env or {}))
+        procs.append(subprocess.Popen(cmd_of_rank(rank), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    return outs
+
+
+def test_two_ranks_hip_compute_sharded_equals_unsharded(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    _launch_two(lambda rank: [sys.executable, str(script)], tmp_path)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_bench_two_rank_rehearsal_prints_one_valid_line(tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--cells", "150000",
+           "--genes", "40", "--perms", "400", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    outs = _launch_two(lambda rank: cmd, tmp_path)
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["genes_total"] == 80 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["permgen_stats"]["verification_fallbacks_max_over_ranks"] == 0
+    assert 0 < line["roofline"]["frac"] < 1.0
+    # strong-scaling shape (configs[3] logic at toy size): 70 genes in total, batches of 16 reuse the resident table
+    cmd2 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--config", "3",
+            "--cells", "140000", "--genes", "70", "--gene-batch", "16", "--perms", "200", "--steps", "1",
+            "--warmup", "0"]
+    outs = _launch_two(lambda rank: cmd2, tmp_path)
+    line = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["config"]["genes_total"] == 70 and line["config"]["genes_per_gpu"] == 35
+
+
+def test_rccl_communicator_world_of_one():
+    """dlopen(librccl) + ncclGetUniqueId + ncclCommInitRank + ncclAllGather + ncclAllReduce on the real device."""
+    from spatialcore_amd._lib import Context, RcclComm
+
+    with Context(0) as ctx:
+        comm = RcclComm(ctx, RcclComm.unique_id(), 1, 0)
+        block = np.arange(12, dtype=np.float64).reshape(3, 4) * 0.5
+        np.testing.assert_array_equal(comm.all_gather(block), block[None])
+        np.testing.assert_array_equal(comm.max_over_ranks([1.5, -2.0]), [1.5, -2.0])
+        comm.barrier()
+        comm.close()
+    with pytest.raises(ValueError):
+        RcclComm(ctx, b"short", 1, 0)
