@@ -1,6 +1,7 @@
 // Context, error and timer plumbing of libspatialcore_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "sc_ctx.h"
 
@@ -131,6 +132,10 @@ int sc_ctx_create(int device, sc_ctx **out)
     }
     sc_ctx *c = new sc_ctx();
     c->device = device;
+    if (const char *v = getenv("SC_MORAN_VARIANT")) {  // development: A/B the scoring kernels on one box
+        const int k = atoi(v);
+        if (k >= 0 && k <= 2) c->moran_variant = k;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

@@ -104,6 +104,7 @@ struct sc_ctx {
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // [tile32][cell][32] float: the raw values again, when they are float32-exact
     bool x32_valid = false, x32_exact = false;
+    int moran_variant = 2;      // float32-source scoring kernel: 0 = r01 form, 1 / 2 = software-pipelined, 4 / 8 cells per stage
     int source_bits_min = 32;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
     int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;

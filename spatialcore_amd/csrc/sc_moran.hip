@@ -606,6 +606,136 @@ __global__ __launch_bounds__(256) void k_moran_perm32(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same statistic, software-pipelined (r02).  In k_moran_perm32 the compiler's schedule leaves ONE random row
+// gather in flight per wavefront (index load -> wait -> gather -> wait -> FMAs -> next gather ...): the kernel is
+// bound by memory latency, not bandwidth.  Here the loop is cut into blocks of CB cells and every stage
+//   (1) loads the inverse-permutation indices of block b + 2,
+//   (2) loads the lag rows of block b + 1 (one coalesced 16-byte load per lane and 4 cells: every lag row is
+//       fetched ONCE per wavefront instead of once per permutation of the wavefront),
+//   (3) issues all CB random row gathers of block b + 1,
+//   (4) waits until only those CB gathers are outstanding (vmcnt counts in order: everything older is there),
+//   (5) parks the lag rows of block b + 1 in the wavefront's private LDS slice (no workgroup barrier anywhere),
+//   (6) multiplies block b: gathered rows from registers, lag rows from LDS (each 16-byte LDS read is a broadcast
+//       to the 8 permutations of the wavefront).
+// CB kilobytes of random rows per wavefront are in flight while it computes.  Every lane adds the same products in
+// the same order as k_moran_perm32: results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+
+template <int CB>
+__global__ __launch_bounds__(256) void k_moran_perm32p(const float *__restrict__ X32t, const double *__restrict__ LagA,
+                                                       const double *__restrict__ LagB,
+                                                       const double *__restrict__ meanA,
+                                                       const double *__restrict__ meanB,
+                                                       const int32_t *__restrict__ inv, double *__restrict__ partial,
+                                                       int64_t n, int64_t pstride, int n_perm, int64_t cells_per_split)
+{
+    static_assert(CB == 4 || CB == 8, "block of 4 or 8 cells");
+    constexpr int NI = CB / 4;   // index vectors (4 cells each) and lag loads (1 KB = 4 cells x 256 B each) per block
+    __shared__ double2 lds_lag[4][2][CB * 16];   // [wavefront][buffer][cell][16 x double2 = 32 genes]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane >> 3, q = lane & 7;
+    const int pbase = blockIdx.y * MP_PERMS_PER_BLOCK + wave * 8;
+    if (pbase >= n_perm) return;  // whole wavefront idle (no workgroup barriers in this kernel)
+    const int p = pbase + r;
+    const int pc = p < n_perm ? p : n_perm - 1;
+    const int64_t c0 = (int64_t)blockIdx.x * cells_per_split;
+    int64_t c1 = c0 + cells_per_split;
+    if (c1 > n) c1 = n;
+    const int32_t *irow = inv + (int64_t)pc * pstride;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X32t) + q;   // row i: X4[i * 8]
+    const double *mp = (q < 4 ? meanA : meanB) + (q & 3) * 4;
+    const double m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+    // cooperative lag load: lane -> (cell lane >> 4 of 4, 16-byte piece lane & 15 of the 256-byte row pair A | B)
+    const int lcell = lane >> 4, lpiece = lane & 15;
+    const double2 *Lsrc = reinterpret_cast<const double2 *>(lpiece < 8 ? LagA : LagB) + (lpiece & 7);   // row j: Lsrc[j * 8]
+    double2 *lw = &lds_lag[wave][0][0];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int64_t nblk = (c1 - c0) / CB;
+
+    int4 ida[NI], idb[NI];          // indices: two blocks ahead, ping-pong
+    double2 lg[NI];                 // lag rows of the next block, on their way to LDS
+    float4 xa[CB], xb[CB];          // gathered rows, ping-pong
+
+    auto load_idx = [&](int4 (&id)[NI], int64_t b) {
+        const int64_t bb = b < nblk ? b : nblk - 1;             // past the end: a harmless reload of the last block
+#pragma unroll
+        for (int k = 0; k < NI; ++k) id[k] = *reinterpret_cast<const int4 *>(irow + c0 + bb * CB + 4 * k);
+    };
+    auto load_lag = [&](int64_t b) {
+        const int64_t bb = b < nblk ? b : nblk - 1;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) lg[k] = Lsrc[(c0 + bb * CB + 4 * k + lcell) * 8];
+    };
+    auto gather = [&](float4 (&x)[CB], const int4 (&id)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            x[4 * k + 0] = X4[(int64_t)id[k].x * 8];
+            x[4 * k + 1] = X4[(int64_t)id[k].y * 8];
+            x[4 * k + 2] = X4[(int64_t)id[k].z * 8];
+            x[4 * k + 3] = X4[(int64_t)id[k].w * 8];
+        }
+    };
+    auto park_lag = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) lw[buf * (CB * 16) + k * 64 + lane] = lg[k];
+    };
+    auto multiply = [&](const float4 (&x)[CB], int buf) {
+        const double2 *lr = lw + buf * (CB * 16) + q * 2;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const double2 la = lr[c * 16], lb = lr[c * 16 + 1];
+            a0 = fma(la.x, (double)x[c].x - m0, a0); a1 = fma(la.y, (double)x[c].y - m1, a1);
+            a2 = fma(lb.x, (double)x[c].z - m2, a2); a3 = fma(lb.y, (double)x[c].w - m3, a3);
+        }
+    };
+    // one pipeline stage for block b: `cur` holds its gathered rows; `nxt` receives block b + 1;
+    // `id_next` holds the indices of block b + 1 and is refilled with those of block b + 3 (its partner with b + 2)
+    auto stage = [&](const float4 (&cur)[CB], float4 (&nxt)[CB], int4 (&id_next)[NI], int64_t b) {
+        load_lag(b + 1);
+        __builtin_amdgcn_sched_barrier(0);   // issue order matters: vmcnt retires in order
+        gather(nxt, id_next);
+        __builtin_amdgcn_sched_barrier(0);
+        load_idx(id_next, b + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // everything older than the CB gathers + NI index loads just issued has arrived
+        if (CB == 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        park_lag((int)((b + 1) & 1));
+        multiply(cur, (int)(b & 1));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nblk > 0) {
+        // prologue: block 0 gathered and its lag rows parked; indices of blocks 1 and 2 on their way
+        load_idx(ida, 0);
+        load_lag(0);
+        gather(xa, ida);
+        load_idx(idb, 1);
+        load_idx(ida, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park_lag(0);
+        int64_t b = 0;
+        for (; b + 2 <= nblk; b += 2) {
+            stage(xa, xb, idb, b);        // idb: block b + 1 -> refilled with b + 3
+            stage(xb, xa, ida, b + 1);    // ida: block b + 2 -> refilled with b + 4
+        }
+        if (b < nblk) stage(xa, xb, idb, b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the speculative loads of the last stage
+    }
+    for (int64_t j = c0 + nblk * CB; j < c1; ++j) {
+        const float4 x = X4[(int64_t)irow[j] * 8];
+        const double2 *L2 = reinterpret_cast<const double2 *>(q < 4 ? LagA : LagB) + (q & 3) * 2;
+        const double2 la = L2[j * 8], lb = L2[j * 8 + 1];
+        a0 = fma(la.x, (double)x.x - m0, a0); a1 = fma(la.y, (double)x.y - m1, a1);
+        a2 = fma(lb.x, (double)x.z - m2, a2); a3 = fma(lb.y, (double)x.w - m3, a3);
+    }
+    if (p < n_perm) {
+        double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)blockIdx.x * n_perm + p) * 32 + 4 * q) / 2;
+        out[0] = make_double2(a0, a1);
+        out[1] = make_double2(a2, a3);
+    }
+}
+
 // sims[p0 + p][32 t + slot] = scale[32 t + slot] * sum_s partial[t][s][p][slot], slot < 32 (ascending s), for every
 // 32-gene tile pair t = blockIdx.y of a chunk in one launch
 __global__ __launch_bounds__(256) void k_moran_finalize32(const double *__restrict__ partial, int64_t tile_stride,
@@ -766,7 +896,9 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
             const int64_t ta = 2 * t, tb = 2 * t + 1 < T ? 2 * t + 1 : 2 * t;  // odd tile count: B mirrors A, unused
             {
                 KernelTimerScope ts(c, SC_K_MORAN_PERM);
-                hipLaunchKernelGGL(k_moran_perm32, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
+                auto kern = c->moran_variant == 0 ? k_moran_perm32
+                            : c->moran_variant == 1 ? k_moran_perm32p<4> : k_moran_perm32p<8>;
+                hipLaunchKernelGGL(kern, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
                                    c->X32.as<float>() + (size_t)t * n * 32, c->Lag.as<double>() + ta * tile_elems,
                                    c->Lag.as<double>() + tb * tile_elems, c->g_mean.as<double>() + ta * SC_TILE,
                                    c->g_mean.as<double>() + tb * SC_TILE, c->inv.as<int32_t>() + p0 * c->p_stride,
@@ -879,7 +1011,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     SC_TRY(sc_perm_alloc(c, n, n_perm));
     if (!c->stream2) {  // the generator chain is the critical path: highest priority (plain stream if refused)
         int prio_lo = 0, prio_hi = 0;
-        if (getenv("SC_NO_STREAM_PRIORITY") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+        if (!getenv("SC_STREAM_PRIORITY") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
             (void)hipGetLastError();
             c->stream2 = nullptr;
@@ -987,6 +1119,12 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
 {
     hipStream_t main_stream = c->stream;
     if (c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n)) {
+        // r02: plain streams only.  With CU-masked or prioritised streams in the process, kernels that run next to
+        // kernels of other queues were measured to compute WRONG values now and then (a wavefront of k_raw_stream
+        // with a wrong 64-bit shift, ~50 wavefronts per 1M x 1000 job; profiles/r02_gpu_sharing_raw_stream_corruption.txt):
+        // every r01 pipeline run at bench size drew some non-numpy permutations.  Plain streams are exact
+        // (scripts/pipeline_soak.py); SC_CU_MASK=1 / SC_STREAM_PRIORITY=1 re-enable the old behaviour for experiments.
+        if (!getenv("SC_CU_MASK")) c->stream_score_failed = true;
         if (!c->stream_score && !c->stream_score_failed) {
             // Best effort: without CU masks (unsupported runtime, odd CU count) the pipeline still runs, the generator's
             // launches just queue behind the scoring workgroups more often.

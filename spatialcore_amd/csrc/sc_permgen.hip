@@ -1046,7 +1046,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         SC_TRY(c->pg_events.ensure(sizeof(uint16_t) * (size_t)PHI_RING * 2 * PHI_MAX_EV, &c->mem));
         SC_TRY(c->pg_hard.ensure((size_t)n_blocks + 1, &c->mem));
         int prio_lo = 0, prio_hi = 0;  // the generator is the critical path of its callers (plain streams if refused)
-        const bool prio = !getenv("SC_NO_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
+        const bool prio = getenv("SC_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
         for (hipStream_t &sp : c->stream_pg) {
             if (sp) continue;
             if (!prio || hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio_hi) != hipSuccess) {

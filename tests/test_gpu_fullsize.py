@@ -144,6 +144,34 @@ def test_config1_at_size_bench_path_p1000(big, oracle):
                                rtol=1e-9, atol=1e-13)
 
 
+def test_pipeline_is_exact_next_to_other_kernels_at_bench_size(big):
+    """Regression for the r02 finding (profiles/r02_gpu_sharing_raw_stream_corruption.txt): with CU-masked or
+    prioritised streams in the process, sc_moran_seeded at bench size drew ~50 wrong wavefronts of raw stream per job
+    whenever other kernels (here: the kNN / graph build enqueued right before, the lag and moments kernels) ran next
+    to the generator -- every repetition had dozens of non-numpy permutations.  Plain streams are exact: each
+    repetition must equal the two-step path fed with the HOST generator's table in every bit, state included."""
+    from spatialcore_amd import _lib
+
+    ctx, coords, _ = big
+    G, P = 160, 1000
+    X = np.random.default_rng(11).poisson(1.0, (N, G)).astype(np.float32)
+    ctx.knn(coords, K, fetch=False)
+    ctx.graph_from_knn(1.0 / K)
+    ctx.set_expression(X, np.arange(G))
+    wh = _lib.rng_state_words(np.random.default_rng(0))
+    ctx.set_permutations(_lib.perm_numpy_host(wh, N, P))
+    ref = ctx.moran(P)
+    for rep in range(3):
+        ctx.knn(coords, K, fetch=False)             # asynchronous: still running when the generator starts
+        ctx.graph_from_knn(1.0 / K)
+        w = _lib.rng_state_words(np.random.default_rng(0))
+        out = ctx.moran_seeded(w, P)
+        np.testing.assert_array_equal(w, wh, err_msg=f"generator state, repetition {rep}")
+        bad = np.flatnonzero((out["sims"] != ref["sims"]).any(axis=1))
+        assert bad.size == 0, f"repetition {rep}: {bad.size} permutations differ, first {bad[:5].tolist()}"
+        np.testing.assert_array_equal(out["count_ge"], ref["count_ge"])
+
+
 def test_config3_shape_radius_graph_and_lee_pairs(big, oracle):
     """BASELINE configs[2] shape: 1M cells, radius graph r = 30 um, Lee's L for 100 x 100 gene pairs
     (observed statistic; the reference has no radius option for Lee, so this is the kernel-level path)."""
