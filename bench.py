@@ -170,9 +170,9 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline + oracle verification leg")
     ap.add_argument("--no-public-api", action="store_true")
-    ap.add_argument("--source-bits", type=int, default=32, choices=(32, 64),
+    ap.add_argument("--source-bits", type=int, default=16, choices=(16, 32, 64),
                     help="narrowest exact copy of the expression values the permutation kernel may gather "
-                         "(32: float32 raw values, 64: the general fp64 kernel)")
+                         "(16: uint16 for count data, 32: float32 raw values, 64: the general fp64 kernel)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and exchange through files (RCCL refuses duplicate "
                          "devices); exercises the N > 1 code path on a 1-GPU box; never a measurement")
@@ -280,8 +280,8 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         value = G_total * args.steps / elapsed
         source_bits = ctx.moran_source_bits()
-        kernel_name = {32: "k_moran_perm32", 64: "k_moran_perm"}[source_bits]
-        genes_per_launch = {32: 32, 64: 16}[source_bits]
+        kernel_name = {16: "k_moran_perm16p", 32: "k_moran_perm32", 64: "k_moran_perm"}[source_bits]
+        genes_per_launch = {16: 64, 32: 32, 64: 16}[source_bits]
         launches_per_step = max(perm_launches // max(args.steps, 1), 1)
         avg_ms = perm_ms / max(perm_launches, 1)
         G_pad = -(-batch // genes_per_launch) * genes_per_launch * len(batches)
@@ -330,7 +330,7 @@ def main() -> None:
                                    + (" (BASELINE configs[1])" if (n, genes_arg, P, k, strong) == (1_000_000, 500, 1000, 15, False)
                                       else " (BASELINE configs[3])" if (n, genes_arg, P, k, strong) == (5_000_000, 2000, 1000, 15, True)
                                       else " (non-default size)"),
-                       "expression_source": {32: "float32", 64: "float64"}[source_bits],
+                       "expression_source": {16: "uint16 (counts)", 32: "float32", 64: "float64"}[source_bits],
                        "cells": n, "genes_per_gpu": G_mine, "genes_total": G_total, "k": k, "perms": P,
                        "parallelism": f"gene-shard x{world}, one RCCL all-gather of (I, p)"
                                       + (" [file transport, rehearsal]" if rehearse else "")},

@@ -64,12 +64,12 @@ int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
 /* Development aid (scripts/concurrency_probe*.py): raw bytes of one of the generator's device buffers
  * (0 J, 1 raw stream, 2 accept masks, 3 entering counts, 4 block states, 5 scan state, 6 table, 7 inverse table). */
 int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64_t bytes);
-/* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values:
- * float32 when every value is a float32 (32 genes per 128-byte row), else the fp64 tiles (16 genes per row).
- * z = (double)x - mean is rebuilt in registers, so both give the same z.  min_bits (32 or 64; default 32) forbids the
- * narrower source; sc_ctx_moran_source_bits reports what the last scoring call used (64 = the general fp64 kernel).
- * A uint16 source for count data (64 genes per row) was built and measured: only 9 % faster per gene, the kernel then
- * is bound by the L1 traffic of the streamed lag rows; not kept. */
+/* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values,
+ * one 128-byte row per cell and gene group: uint16 when every value is an integer count in [0, 65535] (64 genes per
+ * row), else float32 when every value is a float32 (32 genes), else the fp64 tiles (16 genes).
+ * z = (double)x - mean is rebuilt in registers, so all three give the same z and -- same cell order -- the same sums.
+ * min_bits (16, 32 or 64; default 16) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
+ * scoring call used (64 = the general fp64 kernel). */
 int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
 int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
 /* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream

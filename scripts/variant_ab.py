@@ -10,6 +10,7 @@ rng = np.random.default_rng(42)
 coords = rng.uniform(0, np.sqrt(N) * 10, (N, 2))
 X = rng.poisson(1.0, (N, G)).astype(np.float32)
 ctx = _lib.Context(0)
+ctx.set_moran_source_bits(int(os.environ.get("SC_BITS", 16)))
 ctx.knn(coords, 15, fetch=False); ctx.graph_from_knn(1.0 / 15)
 ctx.set_expression(X, np.arange(G))
 w = _lib.rng_state_words(np.random.default_rng(0))
@@ -20,4 +21,4 @@ for rep in range(3):
     out = ctx.moran(P)
     ms, cnt = ctx.kernel_time(_lib.K_MORAN_PERM)
     print(f"variant {os.environ.get('SC_MORAN_VARIANT', 'default')} N={N} G={G} P={P}: {ms / cnt:.3f} ms per launch ({cnt} launches), "
-          f"gathered rows {P * N * 128 * 1e-9 / (ms / cnt * 1e-3) / 1e3:.2f} TB/s; sims sha {hashlib.sha1(out['sims'].tobytes()).hexdigest()[:12]}", flush=True)
+          f"source bits {ctx.moran_source_bits()}, gathered rows {P * N * 128 * 1e-9 / (ms / cnt * 1e-3) / 1e3:.2f} TB/s; sims sha {hashlib.sha1(out['sims'].tobytes()).hexdigest()[:12]}", flush=True)

@@ -7,6 +7,13 @@
 
 static thread_local char g_err[1024] = "";
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
+// streams that share a hardware queue run strictly one after the other.  The generator / scoring pipeline of
+// sc_moran_seeded uses nine streams whose kernels MUST overlap (a 25-ms scoring launch in front of the generator's
+// sub-millisecond chain launches doubles the step), so the library asks for one hardware queue per stream -- before
+// the runtime initialises, i.e. when the library is loaded, and only if the user has not set the variable.
+__attribute__((constructor)) static void sc_request_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 void sc_set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -134,7 +141,7 @@ int sc_ctx_create(int device, sc_ctx **out)
     c->device = device;
     if (const char *v = getenv("SC_MORAN_VARIANT")) {  // development: A/B the scoring kernels on one box
         const int k = atoi(v);
-        if (k >= 0 && k <= 2) c->moran_variant = k;
+        if (k >= 1 && k <= 2) c->moran_variant = k;
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -177,7 +184,6 @@ int sc_ctx_destroy(sc_ctx *c)
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     for (hipStream_t sp : c->stream_pg)
         if (sp) (void)hipStreamDestroy(sp);
-    if (c->stream_score) (void)hipStreamDestroy(c->stream_score);
     if (c->stream_px) (void)hipStreamDestroy(c->stream_px);
     for (hipEvent_t e : c->pg_ev)
         if (e) (void)hipEventDestroy(e);
@@ -247,8 +253,8 @@ int sc_ctx_set_permgen_mode(sc_ctx *c, int mode)
 int sc_ctx_set_moran_source_bits(sc_ctx *c, int min_bits)
 {
     SC_REQUIRE(c, SC_ERR_INVALID, "null context");
-    SC_REQUIRE(min_bits == 32 || min_bits == 64, SC_ERR_INVALID, "sc_ctx_set_moran_source_bits: %d not in {32, 64}",
-               min_bits);
+    SC_REQUIRE(min_bits == 16 || min_bits == 32 || min_bits == 64, SC_ERR_INVALID,
+               "sc_ctx_set_moran_source_bits: %d not in {16, 32, 64}", min_bits);
     c->source_bits_min = min_bits;
     c->x32_valid = false;  // re-evaluated by the next scoring call
     return SC_OK;

@@ -63,8 +63,6 @@ struct sc_ctx {
     hipStream_t stream2 = nullptr;  // fused permutation/Moran pipeline: rejection scan runs ahead here
     hipStream_t stream3 = nullptr;  // ... and the Fisher-Yates swaps of the scanned chunk here
     hipStream_t stream4 = nullptr;  // ... alternating with this one
-    hipStream_t stream_score = nullptr;  // scoring stream of the fused pipeline: every CU but the few left to the generator
-    bool stream_score_failed = false;    // the runtime refused CU masks: scoring stays on the main stream
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
     hipStream_t stream_px = nullptr;     // ... and verifies + expands a finished chunk here, beside the next chunk's chain
     hipEvent_t pg_ev[34] = {};        // rings of events between the preparation and the chain launches + start marker
@@ -102,10 +100,14 @@ struct sc_ctx {
     int64_t e_n = 0, e_genes = 0, e_tiles = 0;
     int e_dtype = SC_F64;  // dtype of the matrix the tiles were loaded from (the reference's float32 paths depend on it)
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
-    DBuf X32;            // [tile32][cell][32] float: the raw values again, when they are float32-exact
-    bool x32_valid = false, x32_exact = false;
-    int moran_variant = 2;      // float32-source scoring kernel: 0 = r01 form, 1 / 2 = software-pipelined, 4 / 8 cells per stage
-    int source_bits_min = 32;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
+    DBuf X32;            // the raw values again in the narrowest exact type, one 128-byte row per cell and gene group:
+                         // [tile32][cell][32] float (float32-exact values) or [tile64][cell][64] uint16 (counts < 65536)
+    bool x32_valid = false, x32_exact = false;  // the narrow copy was (tried to be) built / is usable
+    int narrow_bits = 64;                       // ... and its element width: 16, 32 (64: none, fp64 tiles only)
+    int moran_variant = 1;      // persistent scoring kernel: 1 = 4 cells per pipeline stage, 2 = 8 (SC_MORAN_VARIANT; development)
+    int n_cus = 0;              // compute units of the device (filled on first use)
+    int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
+    int source_bits_min = 16;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
     int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene

@@ -64,7 +64,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     int64_t tiles = ceil_div64(n_genes, SC_TILE);
     size_t bytes = (size_t)tiles * n * SC_TILE * sizeof(double);
     SC_TRY(c->X.ensure(bytes, &c->mem));
-    size_t gb = (size_t)align_up64(tiles, 2) * SC_TILE * sizeof(double);  // the 32-gene kernel reads 32 means
+    size_t gb = (size_t)align_up64(tiles, 4) * SC_TILE * sizeof(double);  // the 64-gene kernel reads 64 means
     SC_TRY(c->g_mean.ensure(gb, &c->mem));
     SC_TRY(c->g_var.ensure(gb, &c->mem));
     SC_TRY(c->g_z2.ensure(gb, &c->mem));
@@ -75,6 +75,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     c->e_tiles = tiles;
     c->x32_valid = false;
     c->x32_exact = false;
+    c->narrow_bits = 64;
     c->lm_valid = false;
     return SC_OK;
 }
@@ -488,34 +489,52 @@ __global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// A5, half the gathered bytes: the same statistic summed over the TARGET cell,
+// A5 on the narrowest exact copy of the raw values: the same statistic summed over the TARGET cell,
 //
 //   sims[p][g] = scale_g * sum_j lag_g[j] * z_g[inv_p[j]],   inv_p = perm_p^-1,   z = (double)x - mean
 //
-// z is rebuilt in registers from the raw value x, which is exact whenever x is a float32 (AnnData's
-// usual dtype; checked on the device): (double)x - mean is the very subtraction k_center performs, so
-// every product is bit-identical to the fp64-tile kernel's.  The gathered operand is then a 128-byte
-// row of 32 float32 genes instead of a 128-byte row of 16 fp64 genes; the fp64 lag is the streamed,
-// coalesced operand (two 16-gene tiles side by side).  Lane = (permutation r, 4 genes q).
+// z is rebuilt in registers from the raw value x: (double)x - mean is the very subtraction k_center performs, so
+// every product is bit-identical to the fp64-tile kernel's.  The gathered operand is a 128-byte row of
+//   * 64 uint16 genes when every loaded value is an integer count in [0, 65535]  (BITS = 16), else
+//   * 32 float32 genes when every value is a float32 (AnnData's usual dtype)      (BITS = 32),
+// instead of 16 fp64 genes: a quarter / half of the random-row bytes per gene.  The fp64 lag rows are the streamed,
+// coalesced operand and the INVERSE permutation supplies the gather index.
+//
+// Row layout (both widths): the 8 lanes q that share a row own genes {16 t + 2 q, 16 t + 2 q + 1 : t < TG} of the
+// group's TG 16-gene tiles (TG = 4 / 2), stored as the lane's 16 bytes [t][e]: a lane's lag operands are then TG
+// 16-byte LDS reads that are contiguous across q (no bank conflicts), one per lag tile.
 // ------------------------------------------------------------------------------------------------
 
-// X32[t32][cell][32] = (float)X[2*t32 + (slot >> 4)][cell][slot & 15]; *inexact |= (double)(float)x != x
-__global__ __launch_bounds__(256) void k_pack_x32(const double *__restrict__ X, float *__restrict__ X32, int64_t n,
-                                                  int64_t tiles16, int *__restrict__ inexact)
+// Narrow[group][cell][q][t][e] = X[TG * group + t][cell][2 q + e] as uint16 / float; *inexact |= a value does not fit
+template <int BITS>
+__global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ X, uint4 *__restrict__ out, int64_t n,
+                                                     int64_t tiles16, int *__restrict__ inexact)
 {
+    constexpr int TG = BITS == 16 ? 4 : 2;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (cell, q)
     if (t >= n * 8) return;
     const int64_t cell = t >> 3;
     const int q = (int)(t & 7);
-    const int64_t t16 = 2 * (int64_t)blockIdx.y + (q >> 2);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t16 < tiles16) {
-        const double *src = X + t16 * n * SC_TILE + cell * SC_TILE + (q & 3) * 4;
-        const double2 a = reinterpret_cast<const double2 *>(src)[0], b = reinterpret_cast<const double2 *>(src)[1];
-        o = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
-        if ((double)o.x != a.x || (double)o.y != a.y || (double)o.z != b.x || (double)o.w != b.y) atomicOr(inexact, 1);
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    bool bad = false;
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+        const int64_t t16 = TG * (int64_t)blockIdx.y + tt;
+        if (t16 >= tiles16) continue;
+        const double2 v = reinterpret_cast<const double2 *>(X + t16 * n * SC_TILE + cell * SC_TILE)[q];
+        if (BITS == 16) {
+            const uint32_t a = (uint32_t)(v.x >= 0.0 && v.x <= 65535.0 ? v.x : 0.0), b = (uint32_t)(v.y >= 0.0 && v.y <= 65535.0 ? v.y : 0.0);
+            bad |= (double)a != v.x || (double)b != v.y;   // NaN, negative, fractional or too large
+            o[tt] = a | (b << 16);
+        } else {
+            const float a = (float)v.x, b = (float)v.y;
+            bad |= (double)a != v.x || (double)b != v.y;   // (NaN compares unequal: a NaN matrix takes the fp64 kernel)
+            o[2 * tt] = __float_as_uint(a);
+            o[2 * tt + 1] = __float_as_uint(b);
+        }
     }
-    reinterpret_cast<float4 *>(X32)[((int64_t)blockIdx.y * n + cell) * 8 + q] = o;
+    if (bad) atomicOr(inexact, 1);
+    out[((int64_t)blockIdx.y * n + cell) * 8 + q] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 #define INV_BLOCKS_PER_ROW 64
@@ -551,206 +570,203 @@ __global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict
     if (bad) atomicOr(flag, 1);
 }
 
-__global__ __launch_bounds__(256) void k_moran_perm32(const float *__restrict__ X32t, const double *__restrict__ LagA,
-                                                      const double *__restrict__ LagB,
-                                                      const double *__restrict__ meanA,
-                                                      const double *__restrict__ meanB,
-                                                      const int32_t *__restrict__ inv, double *__restrict__ partial,
-                                                      int64_t n, int64_t pstride, int n_perm, int64_t cells_per_split)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane >> 3, q = lane & 7;
-    const int pbase = blockIdx.y * MP_PERMS_PER_BLOCK + wave * 8;
-    if (pbase >= n_perm) return;  // whole wavefront idle (no barriers in this kernel)
-    const int p = pbase + r;
-    const int pc = p < n_perm ? p : n_perm - 1;
-    const int64_t c0 = (int64_t)blockIdx.x * cells_per_split;
-    int64_t c1 = c0 + cells_per_split;
-    if (c1 > n) c1 = n;
-    const int32_t *irow = inv + (int64_t)pc * pstride;
-    const float4 *X4 = reinterpret_cast<const float4 *>(X32t) + q;                 // row j: X4[j * 8]
-    const double2 *L2 = reinterpret_cast<const double2 *>((q < 4 ? LagA : LagB)) + (q & 3) * 2;  // row j: L2[j * 8], +1
-    const double *mp = (q < 4 ? meanA : meanB) + (q & 3) * 4;
-    const double m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int64_t j = c0;  // multiple of 8
-    for (; j + 4 <= c1; j += 4) {
-        const int4 id = *reinterpret_cast<const int4 *>(irow + j);
-        const float4 x0 = X4[(int64_t)id.x * 8];
-        const float4 x1 = X4[(int64_t)id.y * 8];
-        const float4 x2 = X4[(int64_t)id.z * 8];
-        const float4 x3 = X4[(int64_t)id.w * 8];
-        const double2 l0a = L2[(j + 0) * 8], l0b = L2[(j + 0) * 8 + 1];
-        const double2 l1a = L2[(j + 1) * 8], l1b = L2[(j + 1) * 8 + 1];
-        const double2 l2a = L2[(j + 2) * 8], l2b = L2[(j + 2) * 8 + 1];
-        const double2 l3a = L2[(j + 3) * 8], l3b = L2[(j + 3) * 8 + 1];
-        a0 = fma(l0a.x, (double)x0.x - m0, a0); a1 = fma(l0a.y, (double)x0.y - m1, a1);
-        a2 = fma(l0b.x, (double)x0.z - m2, a2); a3 = fma(l0b.y, (double)x0.w - m3, a3);
-        a0 = fma(l1a.x, (double)x1.x - m0, a0); a1 = fma(l1a.y, (double)x1.y - m1, a1);
-        a2 = fma(l1b.x, (double)x1.z - m2, a2); a3 = fma(l1b.y, (double)x1.w - m3, a3);
-        a0 = fma(l2a.x, (double)x2.x - m0, a0); a1 = fma(l2a.y, (double)x2.y - m1, a1);
-        a2 = fma(l2b.x, (double)x2.z - m2, a2); a3 = fma(l2b.y, (double)x2.w - m3, a3);
-        a0 = fma(l3a.x, (double)x3.x - m0, a0); a1 = fma(l3a.y, (double)x3.y - m1, a1);
-        a2 = fma(l3b.x, (double)x3.z - m2, a2); a3 = fma(l3b.y, (double)x3.w - m3, a3);
-    }
-    for (; j < c1; ++j) {
-        const float4 x = X4[(int64_t)irow[j] * 8];
-        const double2 la = L2[j * 8], lb = L2[j * 8 + 1];
-        a0 = fma(la.x, (double)x.x - m0, a0); a1 = fma(la.y, (double)x.y - m1, a1);
-        a2 = fma(lb.x, (double)x.z - m2, a2); a3 = fma(lb.y, (double)x.w - m3, a3);
-    }
-    if (p < n_perm) {
-        double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)blockIdx.x * n_perm + p) * 32 + 4 * q) / 2;
-        out[0] = make_double2(a0, a1);
-        out[1] = make_double2(a2, a3);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The same statistic, software-pipelined (r02).  In k_moran_perm32 the compiler's schedule leaves ONE random row
-// gather in flight per wavefront (index load -> wait -> gather -> wait -> FMAs -> next gather ...): the kernel is
-// bound by memory latency, not bandwidth.  Here the loop is cut into blocks of CB cells and every stage
-//   (1) loads the inverse-permutation indices of block b + 2,
-//   (2) loads the lag rows of block b + 1 (one coalesced 16-byte load per lane and 4 cells: every lag row is
-//       fetched ONCE per wavefront instead of once per permutation of the wavefront),
-//   (3) issues all CB random row gathers of block b + 1,
-//   (4) waits until only those CB gathers are outstanding (vmcnt counts in order: everything older is there),
-//   (5) parks the lag rows of block b + 1 in the wavefront's private LDS slice (no workgroup barrier anywhere),
-//   (6) multiplies block b: gathered rows from registers, lag rows from LDS (each 16-byte LDS read is a broadcast
-//       to the 8 permutations of the wavefront).
-// CB kilobytes of random rows per wavefront are in flight while it computes.  Every lane adds the same products in
-// the same order as k_moran_perm32: results are bit-identical.
+// The scoring kernel: PERSISTENT, one 16-wavefront workgroup per compute unit, wavefronts as independent workers.
+//
+// Work = tasks (gene group, cell split, group of 8 permutations); wavefront w of the grid takes tasks w, w + W,
+// w + 2 W, ... (groups slowest: the chip works on one 128-MB narrow table at a time, which stays in the
+// Infinity Cache).  Lane = (permutation r of the 8, q): it keeps 2 TG fp64 accumulators over the task's cell range --
+// no cross-lane reduction, no workgroup barrier.  A task is software-pipelined in blocks of CB cells:
+//   (1) the lag rows of block b + 1 are loaded cooperatively (one coalesced 16-byte load per lane and piece: every
+//       lag row is fetched ONCE per wavefront, not once per permutation),
+//   (2) all CB random row gathers of block b + 1 are issued (indices were loaded two blocks ahead),
+//   (3) the indices of block b + 3 are loaded,
+//   (4) [wait: only the loads of (2), (3) stay outstanding -- vmcnt retires in order]
+//   (5) the lag rows of block b + 1 are parked in the wavefront's private LDS slice,
+//   (6) block b is multiplied: gathered rows from registers, lag rows from LDS (a broadcast to the 8 permutations).
+// CB kilobytes of random rows are in flight per wavefront while it computes.
+//
+// Why persistent and 1024 threads: with > 64 VGPRs per lane a second 16-wavefront workgroup cannot fit on a compute
+// unit, so a grid of W workgroups occupies exactly W of the 256 compute units and leaves the others EMPTY for the
+// permutation generator that runs beside it (sc_moran_seeded) -- without CU-masked or prioritised streams, which were
+// found to corrupt concurrently running kernels on this platform (see moran_seeded_streams).
+// Sums: per gene, cells ascending inside a split, splits ascending in k_moran_finalize_groups -- the same order for
+// both source widths, so their results are bit-identical (and independent of the grid size).
 // ------------------------------------------------------------------------------------------------
 
-template <int CB>
-__global__ __launch_bounds__(256) void k_moran_perm32p(const float *__restrict__ X32t, const double *__restrict__ LagA,
-                                                       const double *__restrict__ LagB,
-                                                       const double *__restrict__ meanA,
-                                                       const double *__restrict__ meanB,
-                                                       const int32_t *__restrict__ inv, double *__restrict__ partial,
-                                                       int64_t n, int64_t pstride, int n_perm, int64_t cells_per_split)
+#define SCORE_WAVES 16
+
+template <int BITS, int CB>
+__global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
+    const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
+    const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
+    int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
 {
-    static_assert(CB == 4 || CB == 8, "block of 4 or 8 cells");
-    constexpr int NI = CB / 4;   // index vectors (4 cells each) and lag loads (1 KB = 4 cells x 256 B each) per block
-    __shared__ double2 lds_lag[4][2][CB * 16];   // [wavefront][buffer][cell][16 x double2 = 32 genes]
+    static_assert((BITS == 16 || BITS == 32) && (CB == 4 || CB == 8), "source width / block size");
+    constexpr int TG = BITS == 16 ? 4 : 2;       // 16-gene lag tiles per gene group
+    constexpr int ROW = TG * 8;                  // 16-byte pieces of a group's lag row (one cell)
+    constexpr int NI = CB / 4;                   // index vectors per block
+    constexpr int NL = CB * ROW / 64;            // lag pieces per lane and block
+    constexpr int CSTEP = 64 / ROW;              // cells covered by one cooperative lag load
+    __shared__ double2 lds_lag[SCORE_WAVES][2][CB * ROW];   // [wavefront][buffer][cell][ROW]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane >> 3, q = lane & 7;
-    const int pbase = blockIdx.y * MP_PERMS_PER_BLOCK + wave * 8;
-    if (pbase >= n_perm) return;  // whole wavefront idle (no workgroup barriers in this kernel)
-    const int p = pbase + r;
-    const int pc = p < n_perm ? p : n_perm - 1;
-    const int64_t c0 = (int64_t)blockIdx.x * cells_per_split;
-    int64_t c1 = c0 + cells_per_split;
-    if (c1 > n) c1 = n;
-    const int32_t *irow = inv + (int64_t)pc * pstride;
-    const float4 *X4 = reinterpret_cast<const float4 *>(X32t) + q;   // row i: X4[i * 8]
-    const double *mp = (q < 4 ? meanA : meanB) + (q & 3) * 4;
-    const double m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
-    // cooperative lag load: lane -> (cell lane >> 4 of 4, 16-byte piece lane & 15 of the 256-byte row pair A | B)
-    const int lcell = lane >> 4, lpiece = lane & 15;
-    const double2 *Lsrc = reinterpret_cast<const double2 *>(lpiece < 8 ? LagA : LagB) + (lpiece & 7);   // row j: Lsrc[j * 8]
+    const int lcell0 = lane / ROW, ltile = (lane % ROW) >> 3;
     double2 *lw = &lds_lag[wave][0][0];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const int64_t nblk = (c1 - c0) / CB;
+    const int pgroups = (n_perm + 7) >> 3;
+    const int64_t n_tasks = (int64_t)n_groups * n_splits * pgroups;
+    const int64_t worker = (int64_t)blockIdx.x * SCORE_WAVES + wave, workers = (int64_t)gridDim.x * SCORE_WAVES;
 
-    int4 ida[NI], idb[NI];          // indices: two blocks ahead, ping-pong
-    double2 lg[NI];                 // lag rows of the next block, on their way to LDS
-    float4 xa[CB], xb[CB];          // gathered rows, ping-pong
+    for (int64_t task = worker; task < n_tasks; task += workers) {
+        const int pg = (int)(task % pgroups);
+        const int64_t rest = task / pgroups;
+        const int split = (int)(rest % n_splits), grp = (int)(rest / n_splits);
+        const int p = pg * 8 + r;
+        const int pc = p < n_perm ? p : n_perm - 1;
+        const int64_t c0 = (int64_t)split * cells_per_split;
+        int64_t c1 = c0 + cells_per_split;
+        if (c1 > n) c1 = n;
+        const int32_t *irow = inv + (int64_t)pc * pstride;
+        // row i of the group's table at byte offset 128 i (+ 16 q for this lane): a 32-bit offset from a
+        // wavefront-uniform base (n < 2^25 cells, checked by the host), i.e. no 64-bit address arithmetic per gather
+        const char *Xg = reinterpret_cast<const char *>(narrow + (int64_t)grp * n * 8);
+        const uint32_t qoff = (uint32_t)q * 16u;
+        auto row_of = [&](int32_t i) { return *reinterpret_cast<const uint4 *>(Xg + ((uint32_t)i * 128u + qoff)); };
+        const int tiles_left = tiles16 - TG * grp;                                 // lag tiles this group really has
+        const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
+        // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
+        const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (lane & 7);
+        double m[TG][2], acc[TG][2];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const double *mt = mean + (int64_t)(TG * grp + (t < tiles_left ? t : 0)) * SC_TILE + 2 * q;
+            m[t][0] = mt[0]; m[t][1] = mt[1];
+            acc[t][0] = acc[t][1] = 0.0;
+        }
+        const int64_t nblk = (c1 - c0) / CB;
 
-    auto load_idx = [&](int4 (&id)[NI], int64_t b) {
-        const int64_t bb = b < nblk ? b : nblk - 1;             // past the end: a harmless reload of the last block
-#pragma unroll
-        for (int k = 0; k < NI; ++k) id[k] = *reinterpret_cast<const int4 *>(irow + c0 + bb * CB + 4 * k);
-    };
-    auto load_lag = [&](int64_t b) {
-        const int64_t bb = b < nblk ? b : nblk - 1;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) lg[k] = Lsrc[(c0 + bb * CB + 4 * k + lcell) * 8];
-    };
-    auto gather = [&](float4 (&x)[CB], const int4 (&id)[NI]) {
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            x[4 * k + 0] = X4[(int64_t)id[k].x * 8];
-            x[4 * k + 1] = X4[(int64_t)id[k].y * 8];
-            x[4 * k + 2] = X4[(int64_t)id[k].z * 8];
-            x[4 * k + 3] = X4[(int64_t)id[k].w * 8];
-        }
-    };
-    auto park_lag = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < NI; ++k) lw[buf * (CB * 16) + k * 64 + lane] = lg[k];
-    };
-    auto multiply = [&](const float4 (&x)[CB], int buf) {
-        const double2 *lr = lw + buf * (CB * 16) + q * 2;
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const double2 la = lr[c * 16], lb = lr[c * 16 + 1];
-            a0 = fma(la.x, (double)x[c].x - m0, a0); a1 = fma(la.y, (double)x[c].y - m1, a1);
-            a2 = fma(lb.x, (double)x[c].z - m2, a2); a3 = fma(lb.y, (double)x[c].w - m3, a3);
-        }
-    };
-    // one pipeline stage for block b: `cur` holds its gathered rows; `nxt` receives block b + 1;
-    // `id_next` holds the indices of block b + 1 and is refilled with those of block b + 3 (its partner with b + 2)
-    auto stage = [&](const float4 (&cur)[CB], float4 (&nxt)[CB], int4 (&id_next)[NI], int64_t b) {
-        load_lag(b + 1);
-        __builtin_amdgcn_sched_barrier(0);   // issue order matters: vmcnt retires in order
-        gather(nxt, id_next);
-        __builtin_amdgcn_sched_barrier(0);
-        load_idx(id_next, b + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        // everything older than the CB gathers + NI index loads just issued has arrived
-        if (CB == 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        park_lag((int)((b + 1) & 1));
-        multiply(cur, (int)(b & 1));
-        __builtin_amdgcn_sched_barrier(0);
-    };
+        int4 ida[NI], idb[NI];
+        double2 lg0, lg1, lg2, lg3;   // lag pieces on their way to LDS (as many as NL)
+        uint4 xa[CB], xb[CB];
 
-    if (nblk > 0) {
-        // prologue: block 0 gathered and its lag rows parked; indices of blocks 1 and 2 on their way
-        load_idx(ida, 0);
-        load_lag(0);
-        gather(xa, ida);
-        load_idx(idb, 1);
-        load_idx(ida, 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        park_lag(0);
-        int64_t b = 0;
-        for (; b + 2 <= nblk; b += 2) {
-            stage(xa, xb, idb, b);        // idb: block b + 1 -> refilled with b + 3
-            stage(xb, xa, ida, b + 1);    // ida: block b + 2 -> refilled with b + 4
+        auto load_idx = [&](int4 (&id)[NI], int64_t b) {
+            const int64_t bb = b < nblk ? b : nblk - 1;   // past the end: a harmless reload of the last block
+#pragma unroll
+            for (int k = 0; k < NI; ++k) id[k] = *reinterpret_cast<const int4 *>(irow + c0 + bb * CB + 4 * k);
+        };
+        auto load_lag = [&](int64_t b) {
+            const int64_t bb = b < nblk ? b : nblk - 1;
+            const int64_t row0 = c0 + bb * CB + lcell0;
+            lg0 = lsrc[row0 * 8];
+            if constexpr (NL > 1) lg1 = lsrc[(row0 + CSTEP) * 8];
+            if constexpr (NL > 2) { lg2 = lsrc[(row0 + 2 * CSTEP) * 8]; lg3 = lsrc[(row0 + 3 * CSTEP) * 8]; }
+        };
+        auto gather = [&](uint4 (&x)[CB], const int4 (&id)[NI]) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                x[4 * k + 0] = row_of(id[k].x);
+                x[4 * k + 1] = row_of(id[k].y);
+                x[4 * k + 2] = row_of(id[k].z);
+                x[4 * k + 3] = row_of(id[k].w);
+            }
+        };
+        auto park_lag = [&](int buf) {
+            double2 *dst = lw + buf * (CB * ROW) + lane;
+            dst[0] = lg0;
+            if constexpr (NL > 1) dst[64] = lg1;
+            if constexpr (NL > 2) { dst[128] = lg2; dst[192] = lg3; }
+        };
+        auto mul_cell = [&](const uint4 &x, const double2 *lr) {
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const double2 l = lr[t * 8];
+                double v0, v1;
+                if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                acc[t][0] = fma(l.x, v0 - m[t][0], acc[t][0]);
+                acc[t][1] = fma(l.y, v1 - m[t][1], acc[t][1]);
+            }
+        };
+        auto multiply = [&](const uint4 (&x)[CB], int buf) {
+            const double2 *lr = lw + buf * (CB * ROW) + q;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) mul_cell(x[c], lr + c * ROW);
+        };
+        // one stage for block b: `cur` holds its gathered rows; `nxt` receives block b + 1; `id_next` holds the indices
+        // of block b + 1 and is refilled with those of block b + 3 (its partner holds b + 2)
+        auto stage = [&](const uint4 (&cur)[CB], uint4 (&nxt)[CB], int4 (&id_next)[NI], int64_t b) {
+            load_lag(b + 1);
+            __builtin_amdgcn_sched_barrier(0);   // issue order matters: vmcnt retires in order
+            gather(nxt, id_next);
+            __builtin_amdgcn_sched_barrier(0);
+            load_idx(id_next, b + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            park_lag((int)((b + 1) & 1));        // (the compiler's s_waitcnt here leaves the loads of (2), (3) outstanding)
+            multiply(cur, (int)(b & 1));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        if (nblk > 0) {
+            load_idx(ida, 0);
+            load_lag(0);
+            gather(xa, ida);
+            load_idx(idb, 1);
+            load_idx(ida, 2);
+            park_lag(0);
+            int64_t b = 0;
+            for (; b + 2 <= nblk; b += 2) {
+                stage(xa, xb, idb, b);        // idb: block b + 1 -> refilled with b + 3
+                stage(xb, xa, ida, b + 1);    // ida: block b + 2 -> refilled with b + 4
+            }
+            if (b < nblk) stage(xa, xb, idb, b);
         }
-        if (b < nblk) stage(xa, xb, idb, b);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the speculative loads of the last stage
-    }
-    for (int64_t j = c0 + nblk * CB; j < c1; ++j) {
-        const float4 x = X4[(int64_t)irow[j] * 8];
-        const double2 *L2 = reinterpret_cast<const double2 *>(q < 4 ? LagA : LagB) + (q & 3) * 2;
-        const double2 la = L2[j * 8], lb = L2[j * 8 + 1];
-        a0 = fma(la.x, (double)x.x - m0, a0); a1 = fma(la.y, (double)x.y - m1, a1);
-        a2 = fma(lb.x, (double)x.z - m2, a2); a3 = fma(lb.y, (double)x.w - m3, a3);
-    }
-    if (p < n_perm) {
-        double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)blockIdx.x * n_perm + p) * 32 + 4 * q) / 2;
-        out[0] = make_double2(a0, a1);
-        out[1] = make_double2(a2, a3);
+        for (int64_t j = c0 + nblk * CB; j < c1; ++j) {   // ragged tail of the split: straight from global memory
+            const uint4 x = row_of(irow[j]);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const double2 l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
+                double v0, v1;
+                if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                acc[t][0] = fma(l.x, v0 - m[t][0], acc[t][0]);
+                acc[t][1] = fma(l.y, v1 - m[t][1], acc[t][1]);
+            }
+        }
+        if (p < n_perm) {
+            // partial[group][split][perm][16 t + 2 q + e]
+            double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)grp * n_splits + split) * n_perm + p) * ROW + q;
+#pragma unroll
+            for (int t = 0; t < TG; ++t) out[t * 8] = make_double2(acc[t][0], acc[t][1]);
+        }
     }
 }
 
-// sims[p0 + p][32 t + slot] = scale[32 t + slot] * sum_s partial[t][s][p][slot], slot < 32 (ascending s), for every
-// 32-gene tile pair t = blockIdx.y of a chunk in one launch
-__global__ __launch_bounds__(256) void k_moran_finalize32(const double *__restrict__ partial, int64_t tile_stride,
-                                                          const double *__restrict__ scale,
-                                                          double *__restrict__ sims, int n_perm, int splits,
-                                                          int64_t n_genes, int64_t p0)
+// sims[p0 + p][GP grp + slot] = scale * sum_s partial[grp][s][p][slot] (ascending s), for every gene group of a
+// chunk in one launch (GP = genes per group: 64 for the uint16 source, 32 for float32)
+template <int GP>
+__global__ __launch_bounds__(256) void k_moran_finalize_groups(const double *__restrict__ partial,
+                                                               const double *__restrict__ scale,
+                                                               double *__restrict__ sims, int n_perm, int splits,
+                                                               int64_t n_genes, int64_t p0)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int p = t >> 5, slot = t & 31;
-    const int64_t g = 32 * (int64_t)blockIdx.y + slot;
+    const int p = t / GP, slot = t % GP;
+    const int64_t g = GP * (int64_t)blockIdx.y + slot;
     if (p >= n_perm || g >= n_genes) return;
-    const double *pt = partial + (int64_t)blockIdx.y * tile_stride;
+    const double *pt = partial + (int64_t)blockIdx.y * splits * n_perm * GP;
     double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += pt[((int64_t)k * n_perm + p) * 32 + slot];
+    for (int k = 0; k < splits; ++k) s += pt[((int64_t)k * n_perm + p) * GP + slot];
     sims[(p0 + p) * n_genes + g] = scale[g] * s;
+}
+
+// cell range of one scoring task: a function of n ALONE (results must not depend on the chunking of the
+// permutations or on the source width): >= 2048 cells, a multiple of 8, at most 512 splits
+static int64_t score_cells_per_split(int64_t n)
+{
+    int64_t cps = align_up64(ceil_div64(n, 512), 8);
+    return cps < 2048 ? 2048 : cps;
 }
 
 static int pick_splits(int64_t n, int n_perm_tiles, int64_t *cells_per_split)
@@ -795,21 +811,37 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm)
                        (double)n / c->s0, T * SC_TILE);
     SC_HIP(hipGetLastError());
     if (n_perm > 0) {
-        // partial sums for one chunk of permutations (<= PERM_CHUNK, or all of them in the unfused call)
+        // partial sums for one chunk of permutations (<= PERM_CHUNK): the persistent kernel keeps one row per
+        // (64-gene-padded gene, split, permutation); the fp64 kernel one per (16 genes, split, permutation)
         int64_t cps = 0;
-        int splits = pick_splits(n, 1, &cps);  // upper bound on the split count
-        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)splits * (size_t)n_perm * 32 * (size_t)((T + 1) / 2), &c->mem));
-        if (!c->x32_valid) {  // float32 copy of the raw values for the half-traffic kernel, if that is exact
-            const int64_t T32 = (T + 1) / 2;
-            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));
+        const int splits64 = pick_splits(n, 1, &cps);  // upper bound on the fp64 kernel's split count
+        const int64_t score_splits = ceil_div64(n, score_cells_per_split(n));
+        const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 64);
+        const size_t wide_rows = (size_t)splits64 * SC_TILE;
+        SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
+        if (!c->x32_valid) {
+            // the narrowest EXACT copy of the raw values the caller allows: uint16 (64 genes per 128-byte row) for
+            // count data, else float32 (32 genes per row), else none (fp64 tiles, 16 genes per row)
+            const int64_t T32 = (T + 1) / 2, T64 = (T + 3) / 4;
+            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= T64 * n * 128 bytes
             SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
-            SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_pack_x32, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)T32), dim3(256), 0, c->stream,
-                               c->X.as<double>(), c->X32.as<float>(), n, T, c->perm_flag.as<int>());
-            int inexact = 0;
-            SC_HIP(hipMemcpyAsync(&inexact, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            SC_HIP(hipStreamSynchronize(c->stream));
-            c->x32_exact = (inexact == 0);
+            c->narrow_bits = 64;
+            for (int bits = c->source_bits_min <= 16 ? 16 : 32; bits <= 32 && c->narrow_bits == 64 && c->source_bits_min <= 32;
+                 bits += 16) {
+                SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
+                const dim3 grid((unsigned)ceil_div64(n * 8, 256), (unsigned)(bits == 16 ? T64 : T32));
+                if (bits == 16)
+                    hipLaunchKernelGGL(k_pack_narrow<16>, grid, dim3(256), 0, c->stream, c->X.as<double>(),
+                                       c->X32.as<uint4>(), n, T, c->perm_flag.as<int>());
+                else
+                    hipLaunchKernelGGL(k_pack_narrow<32>, grid, dim3(256), 0, c->stream, c->X.as<double>(),
+                                       c->X32.as<uint4>(), n, T, c->perm_flag.as<int>());
+                int inexact = 0;
+                SC_HIP(hipMemcpyAsync(&inexact, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                SC_HIP(hipStreamSynchronize(c->stream));
+                if (!inexact) c->narrow_bits = bits;
+            }
+            c->x32_exact = c->narrow_bits < 64;
             c->x32_valid = true;
         }
     }
@@ -849,7 +881,7 @@ int sc_perm_forward_ensure(sc_ctx *c)
 // narrowest exact source the scoring may gather: 32 (float32 raw values), 64 (the fp64 kernel)
 static int moran_source_bits(const sc_ctx *c)
 {
-    return c->source_bits_min <= 32 && c->x32_exact ? 32 : 64;
+    return c->x32_exact ? c->narrow_bits : 64;
 }
 
 static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
@@ -875,44 +907,56 @@ static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
     return SC_OK;
 }
 
-// score permutations [p0, p1) of the active table for every gene tile (on the context stream).
-// bits: 64 = fp64 kernel; 32 = gather the raw float32 values through the inverse permutation (needs inverse rows
-// [p0, p1); invert_here launches that inversion first).
+// score permutations [p0, p1) of the active table for every gene (on the context stream).
+// bits: 64 = fp64 kernel over the permutation rows; 16 / 32 = the persistent kernel gathers the narrow raw values
+// through the INVERSE permutation (needs inverse rows [p0, p1); invert_here launches that inversion first).
 static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool invert_here)
 {
     const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
     const size_t tile_elems = (size_t)n * SC_TILE;
     const int cnt = (int)(p1 - p0);
     if (cnt <= 0) return SC_OK;
-    const int ptiles = (int)ceil_div64(cnt, MP_PERMS_PER_BLOCK);
-    int64_t cps = 0;
-    const int splits = pick_splits(n, ptiles, &cps);
     c->last_source_bits = bits;
-    if (bits == 32) {
+    if (bits <= 32) {
+        SC_REQUIRE(n < ((int64_t)1 << 25), SC_ERR_INVALID, "the narrow-source scoring kernel addresses rows with 32-bit "
+                   "byte offsets: n_cells must be < 2^25 (got %lld); use sc_ctx_set_moran_source_bits(ctx, 64)", (long long)n);
         if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
-        const int64_t T32 = (T + 1) / 2;
-        const int64_t pt_stride = (int64_t)splits * cnt * 32;  // partial sums of one tile pair
-        for (int64_t t = 0; t < T32; ++t) {
-            const int64_t ta = 2 * t, tb = 2 * t + 1 < T ? 2 * t + 1 : 2 * t;  // odd tile count: B mirrors A, unused
-            {
-                KernelTimerScope ts(c, SC_K_MORAN_PERM);
-                auto kern = c->moran_variant == 0 ? k_moran_perm32
-                            : c->moran_variant == 1 ? k_moran_perm32p<4> : k_moran_perm32p<8>;
-                hipLaunchKernelGGL(kern, dim3((unsigned)splits, (unsigned)ptiles), dim3(256), 0, c->stream,
-                                   c->X32.as<float>() + (size_t)t * n * 32, c->Lag.as<double>() + ta * tile_elems,
-                                   c->Lag.as<double>() + tb * tile_elems, c->g_mean.as<double>() + ta * SC_TILE,
-                                   c->g_mean.as<double>() + tb * SC_TILE, c->inv.as<int32_t>() + p0 * c->p_stride,
-                                   c->partial.as<double>() + t * pt_stride, n, c->p_stride, cnt, cps);
-            }
+        const int GP = bits == 16 ? 64 : 32;
+        const int groups = (int)ceil_div64(T * SC_TILE, GP);
+        const int64_t cps = score_cells_per_split(n);
+        const int splits = (int)ceil_div64(n, cps);
+        // one workgroup per compute unit: all of them, or all but those left to a generator that runs beside us
+        if (c->n_cus <= 0) {
+            hipDeviceProp_t prop;
+            SC_HIP(hipGetDeviceProperties(&prop, c->device));
+            c->n_cus = prop.multiProcessorCount;
         }
-        // one reduction launch for all tile pairs of the chunk (between the scoring launches it would serialise
-        // 16 small kernels per chunk on the scoring stream)
-        hipLaunchKernelGGL(k_moran_finalize32, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256), (unsigned)T32),
-                           dim3(256), 0, c->stream, c->partial.as<double>(), pt_stride, c->g_scale.as<double>(),
-                           c->sims.as<double>(), cnt, splits, G, p0);
+        int wgs = c->n_cus - (c->score_leave_cus > 0 && c->score_leave_cus < c->n_cus ? c->score_leave_cus : 0);
+        const int64_t tasks = (int64_t)groups * splits * ((cnt + 7) / 8);
+        if ((int64_t)wgs * SCORE_WAVES > tasks) wgs = (int)ceil_div64(tasks, SCORE_WAVES);
+        {
+            KernelTimerScope ts(c, SC_K_MORAN_PERM);
+            auto kern = bits == 16 ? (c->moran_variant == 2 ? k_moran_score<16, 8> : k_moran_score<16, 4>)
+                                   : (c->moran_variant == 2 ? k_moran_score<32, 8> : k_moran_score<32, 4>);
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, c->X32.as<uint4>(),
+                               c->Lag.as<double>(), (int64_t)tile_elems, (int)T, c->g_mean.as<double>(),
+                               c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), n, c->p_stride, cnt, cps,
+                               splits, groups);
+        }
+        if (bits == 16)
+            hipLaunchKernelGGL(k_moran_finalize_groups<64>, dim3((unsigned)ceil_div64((int64_t)cnt * 64, 256), (unsigned)groups),
+                               dim3(256), 0, c->stream, c->partial.as<double>(), c->g_scale.as<double>(),
+                               c->sims.as<double>(), cnt, splits, G, p0);
+        else
+            hipLaunchKernelGGL(k_moran_finalize_groups<32>, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256), (unsigned)groups),
+                               dim3(256), 0, c->stream, c->partial.as<double>(), c->g_scale.as<double>(),
+                               c->sims.as<double>(), cnt, splits, G, p0);
         SC_HIP(hipGetLastError());
         return SC_OK;
     }
+    const int ptiles = (int)ceil_div64(cnt, MP_PERMS_PER_BLOCK);
+    int64_t cps = 0;
+    const int splits = pick_splits(n, ptiles, &cps);
     for (int64_t t = 0; t < T; ++t) {
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
@@ -976,14 +1020,14 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     // the permutation rows themselves are materialised only when something needs them (the fp64 kernel, or rows
     // whose inverse is not there yet).
     const bool inverse_suffices = n_perm > 0 && c->perm_bijective && c->inv_rows_valid >= n_perm &&
-                                  moran_source_bits(c) == 32;
+                                  moran_source_bits(c) <= 32;
     if (n_perm > 0 && !inverse_suffices) SC_TRY(sc_perm_forward_ensure(c));
     int bits = 64;
     SC_TRY(moran_choose_path(c, n_perm, &bits));
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) {
         const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
         SC_TRY(moran_perm_range(c, p0, p1, bits, p1 > c->inv_rows_valid));
-        if (bits == 32 && p1 > c->inv_rows_valid) c->inv_rows_valid = p1;
+        if (bits <= 32 && p1 > c->inv_rows_valid) c->inv_rows_valid = p1;
     }
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
@@ -1074,7 +1118,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     const int bits = moran_source_bits(c);
     // (a float32 matrix with NaNs fails the exactness test of its float32 copy: the fp64 kernel then needs the
     // permutation rows themselves, made below from the inverse rows chunk by chunk)
-    const bool need_forward = inverse_only && bits != 32;
+    const bool need_forward = inverse_only && bits > 32;
     c->perm_forward_valid = !inverse_only || need_forward;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
         if (k + 1 < chunks) rc = generate(k + 1);
@@ -1107,62 +1151,28 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
 }
 
 #ifndef SCORE_RESERVED_CUS
-#define SCORE_RESERVED_CUS 8
+#define SCORE_RESERVED_CUS 32
 #endif
-// SCORE_RESERVED_CUS: compute units the scoring stream leaves to the generator's many short launches
-
-// The scoring kernel fills every CU it may use with workgroups that live for milliseconds; the block-parallel
-// generator is a chain of sub-millisecond launches that must not queue behind them.  While it is in use, scoring
-// runs on a stream whose CU mask leaves a few CUs out; the generator streams may use the whole chip.
+// SCORE_RESERVED_CUS: compute units the persistent scoring kernel leaves EMPTY for the generator that runs beside it.
+//
+// The scoring kernel would fill every compute unit with wavefronts that live for milliseconds, and the generator is
+// a chain of sub-millisecond launches (most of them 1024-thread workgroups that need a nearly empty compute unit)
+// that must not queue behind them.  r01 kept them apart with CU-masked and prioritised streams; r02 does it by the
+// scoring kernel's own shape -- a grid of (CUs - reserved) one-per-CU workgroups (see k_moran_score) on plain streams,
+// each stream on its own hardware queue (GPU_MAX_HW_QUEUES, see sc_api.hip).  Measured on one box, 1M cells x 500
+// genes x 1000 permutations: reserved 16 -> 1406 genes/s, 32 -> 1716, 48 -> no better; with the runtime's default
+// of 4 shared hardware queues 1174 (the chain's launches queue behind 25-ms scoring launches).
 static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
                                 int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
 {
-    hipStream_t main_stream = c->stream;
-    if (c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n)) {
-        // r02: plain streams only.  With CU-masked or prioritised streams in the process, kernels that run next to
-        // kernels of other queues were measured to compute WRONG values now and then (a wavefront of k_raw_stream
-        // with a wrong 64-bit shift, ~50 wavefronts per 1M x 1000 job; profiles/r02_gpu_sharing_raw_stream_corruption.txt):
-        // every r01 pipeline run at bench size drew some non-numpy permutations.  Plain streams are exact
-        // (scripts/pipeline_soak.py); SC_CU_MASK=1 / SC_STREAM_PRIORITY=1 re-enable the old behaviour for experiments.
-        if (!getenv("SC_CU_MASK")) c->stream_score_failed = true;
-        if (!c->stream_score && !c->stream_score_failed) {
-            // Best effort: without CU masks (unsupported runtime, odd CU count) the pipeline still runs, the generator's
-            // launches just queue behind the scoring workgroups more often.
-            hipDeviceProp_t prop;
-            SC_HIP(hipGetDeviceProperties(&prop, c->device));
-            const int cus = prop.multiProcessorCount;
-            std::vector<uint32_t> mask((size_t)((cus + 31) / 32), 0u);
-            for (int k = SCORE_RESERVED_CUS; k < cus; ++k) mask[(size_t)(k / 32)] |= 1u << (k % 32);
-            hipStream_t score = nullptr, sw3 = nullptr, sw4 = nullptr;
-            const bool ok = cus > 2 * SCORE_RESERVED_CUS &&
-                            hipExtStreamCreateWithCUMask(&score, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
-                            hipExtStreamCreateWithCUMask(&sw3, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
-                            hipExtStreamCreateWithCUMask(&sw4, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-            if (ok) {
-                // the swaps and the inverse tables of the pipeline stay off the generator's CUs as well
-                for (hipStream_t *sw : {&c->stream3, &c->stream4})
-                    if (*sw) { SC_HIP(hipStreamSynchronize(*sw)); SC_HIP(hipStreamDestroy(*sw)); *sw = nullptr; }
-                c->stream_score = score; c->stream3 = sw3; c->stream4 = sw4;
-            } else {
-                (void)hipGetLastError();
-                for (hipStream_t x : {score, sw3, sw4})
-                    if (x) (void)hipStreamDestroy(x);
-                c->stream_score_failed = true;
-            }
-        }
-        if (c->stream_score) {
-            SC_HIP(hipStreamSynchronize(main_stream));
-            c->stream = c->stream_score;
-        }
-    }
     const int ahead = c->pg_ahead;
-    c->pg_ahead = PIPE_AHEAD;  // the preparation launches wait for CUs the scoring workgroups hold for milliseconds
+    int leave = c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n) ? SCORE_RESERVED_CUS : 8;
+    if (const char *v = getenv("SC_SCORE_LEAVE_CUS")) leave = atoi(v);  // development: sweep the reservation
+    c->pg_ahead = PIPE_AHEAD;
+    c->score_leave_cus = leave;
     const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+    c->score_leave_cus = 0;
     c->pg_ahead = ahead;
-    if (c->stream != main_stream) {
-        (void)hipStreamSynchronize(c->stream);
-        c->stream = main_stream;
-    }
     return rc;
 }
 

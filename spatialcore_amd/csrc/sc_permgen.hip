@@ -67,6 +67,28 @@ __host__ __device__ static inline uint64_t xsl_rr(u128 s)
     return (x >> r) | (x << ((64 - r) & 63));
 }
 
+// The same rotation from 32-bit funnel shifts only (v_alignbit_b32) -- the form the DEVICE uses.
+// r02 finding: with the plain form above, the compiler emits v_lshlrev_b64 / v_lshrrev_b64 with a per-lane shift
+// amount, and k_raw_stream then wrote WRONG outputs for whole wavefronts (the left-shifted half of the rotation)
+// whenever kernels of other hardware queues ran on the chip at the same time -- never when it ran alone:
+// ~50 wavefronts per 1M x 1000 job inside the Moran pipeline, i.e. every r01 pipeline run at bench size drew some
+// non-numpy permutations; also when a second process used the GPU.  Same job, same box, A/B by kernel variant
+// (scripts/pipeline_soak.py, 3 repetitions each): 64-bit shifts 38k-139k wrong draws per job; with an added
+// s_waitcnt after every store 1.5-2.1M; this form 0, and every statistic bit-equal to the host generator's.
+// Evidence and decoding of the wrong words: profiles/r02_gpu_sharing_raw_stream_corruption.txt.
+__device__ static inline uint64_t xsl_rr32(u128 s)
+{
+    const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s;
+    const uint64_t x = hi ^ lo;
+    const uint32_t r = (uint32_t)(hi >> 58);
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    if (r & 32) { const uint32_t t = xl; xl = xh; xh = t; }          // rotate by 32: swap the halves
+    const uint32_t k = r & 31;
+    const uint32_t ol = __builtin_amdgcn_alignbit(xh, xl, k);         // ({xh, xl} >> k) low word
+    const uint32_t oh = __builtin_amdgcn_alignbit(xl, xh, k);
+    return ((uint64_t)oh << 32) | ol;
+}
+
 // ------------------------------------------------------------------------------------------------
 // A0: the raw 32-bit stream, stored in the layout the scan reads.
 //
@@ -114,8 +136,8 @@ __global__ __launch_bounds__(256) void k_raw_stream(uint64_t st_hi, uint64_t st_
     const Affine j = lcg_pow(inc, m + 1);  // output m is made from the state after m + 1 steps
     u128 s = j.mult * state0 + j.plus;
     for (int k = 0; k < RAW_BLOCKS && b < n_blocks; ++k, ++b) {
-        const uint64_t o0 = xsl_rr(s);
-        const uint64_t o1 = xsl_rr(s * mult + inc);
+        const uint64_t o0 = xsl_rr32(s);
+        const uint64_t o1 = xsl_rr32(s * mult + inc);
         uint4 v;
         v.x = (uint32_t)o0; v.y = (uint32_t)(o0 >> 32); v.z = (uint32_t)o1; v.w = (uint32_t)(o1 >> 32);
         *reinterpret_cast<uint4 *>(raw + b * SCAN_BLOCK + (uint64_t)g * (4 * SCAN_THREADS) + 4ull * tau) = v;

@@ -126,7 +126,7 @@ def test_config1_at_size_bench_path_p1000(big, oracle):
     before = ctx.permgen_stats()
     one = ctx.moran_seeded(w, P)
     par, seq, fallbacks = (a - b for a, b in zip(ctx.permgen_stats()[:3], before[:3]))
-    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 32
+    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 32      # fractional values: float32 source
     wh = _lib.rng_state_words(np.random.default_rng(0))
     table = _lib.perm_numpy_host(wh, N, P)
     np.testing.assert_array_equal(w, wh)                                # generator state after 1000 x 1M steps
@@ -145,11 +145,11 @@ def test_config1_at_size_bench_path_p1000(big, oracle):
 
 
 def test_pipeline_is_exact_next_to_other_kernels_at_bench_size(big):
-    """Regression for the r02 finding (profiles/r02_gpu_sharing_raw_stream_corruption.txt): with CU-masked or
-    prioritised streams in the process, sc_moran_seeded at bench size drew ~50 wrong wavefronts of raw stream per job
-    whenever other kernels (here: the kNN / graph build enqueued right before, the lag and moments kernels) ran next
-    to the generator -- every repetition had dozens of non-numpy permutations.  Plain streams are exact: each
-    repetition must equal the two-step path fed with the HOST generator's table in every bit, state included."""
+    """Regression for the r02 finding (profiles/r02_gpu_sharing_raw_stream_corruption.txt): the raw-stream kernel's
+    64-bit variable shifts came out wrong for whole wavefronts whenever kernels of other hardware queues ran beside it
+    (here: the kNN / graph build enqueued right before, the lag and moments kernels, the scoring kernel) -- at bench
+    size every repetition of the r01 pipeline drew dozens of non-numpy permutations.  With the 32-bit funnel-shift
+    form each repetition must equal the two-step path fed with the HOST generator's table in every bit, state included."""
     from spatialcore_amd import _lib
 
     ctx, coords, _ = big
@@ -166,6 +166,7 @@ def test_pipeline_is_exact_next_to_other_kernels_at_bench_size(big):
         ctx.graph_from_knn(1.0 / K)
         w = _lib.rng_state_words(np.random.default_rng(0))
         out = ctx.moran_seeded(w, P)
+        assert ctx.moran_source_bits() == 16                      # Poisson counts: uint16 source
         np.testing.assert_array_equal(w, wh, err_msg=f"generator state, repetition {rep}")
         bad = np.flatnonzero((out["sims"] != ref["sims"]).any(axis=1))
         assert bad.size == 0, f"repetition {rep}: {bad.size} permutations differ, first {bad[:5].tolist()}"
