@@ -136,11 +136,15 @@ def public_api_rate(coords, X, k: int, P: int, seed: int, device: int):
     """G / wall time of morans_i(adata, genes=all, n_neighbors=k, n_permutations=P, seed=seed) on a float32 CSR
     AnnData: everything the user's call pays (validation, PCIe upload of the matrix, graph, obsp side effects,
     DataFrame) -- SURVEY 8(d)'s definition of the metric.  Second of two calls (the first also pays hipMalloc)."""
+    import logging
+
     import pandas as pd
     from scipy import sparse
 
     from spatialcore_amd import SimpleAnnData
     from spatialcore_amd.spatial import morans_i
+
+    logging.getLogger("spatialcore_amd").setLevel(logging.WARNING)   # stdout carries exactly one JSON line
 
     Xs = sparse.csr_matrix(X)
     ad = SimpleAnnData(Xs, obs=pd.DataFrame(index=pd.RangeIndex(X.shape[0]).astype(str)),
@@ -280,16 +284,18 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         value = G_total * args.steps / elapsed
         source_bits = ctx.moran_source_bits()
-        kernel_name = {16: "k_moran_perm16p", 32: "k_moran_perm32", 64: "k_moran_perm"}[source_bits]
-        genes_per_launch = {16: 64, 32: 32, 64: 16}[source_bits]
+        kernel_name = {16: "k_moran_score", 32: "k_moran_score", 64: "k_moran_perm"}[source_bits]
+        genes_per_launch = {16: 64, 32: 32, 64: 16}[source_bits]   # genes served by one gathered 128-byte row
         launches_per_step = max(perm_launches // max(args.steps, 1), 1)
         avg_ms = perm_ms / max(perm_launches, 1)
         G_pad = -(-batch // genes_per_launch) * genes_per_launch * len(batches)
         # (1) what THIS kernel's formulation has to move per step (its algorithmic bytes): one 128-byte row of raw
-        #     values per (permutation, cell, launch tile), one 4-byte index per (permutation, cell, tile), and the
-        #     streamed fp64 lag rows once per launch (16 B x genes_per_launch x cells).
-        tiles = G_pad // genes_per_launch
-        kernel_bytes_step = tiles * (P * n * (128.0 + 4.0)) + launches_per_step * n * 8.0 * genes_per_launch
+        #     values and one 4-byte index per (permutation, cell, gene group of 64 / 32 / 16 genes), and the fp64 lag
+        #     rows of every gene once per launch (a launch = one chunk of permutations x all gene groups for the
+        #     persistent narrow-source kernel, x one 16-gene tile for the fp64 kernel).
+        groups = G_pad // genes_per_launch
+        lag_passes = launches_per_step if source_bits < 64 else launches_per_step / max(groups, 1)
+        kernel_bytes_step = groups * (P * n * (128.0 + 4.0)) + lag_passes * n * 8.0 * G_pad
         kernel_bytes = kernel_bytes_step / launches_per_step
         achieved = kernel_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
         # (2) SURVEY.md 8(d)'s streaming model (the contract's per-unit figure: 16 B per (permutation, gene, cell) for

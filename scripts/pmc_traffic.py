@@ -2,9 +2,9 @@
 
 Usage (on the GPU box, after two separate counter passes of the same command):
 
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write k_moran_perm32 gpurun_out/pmc_out
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api
+    python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write k_moran_score gpurun_out/pmc_out
 
 Writes <out>/<kernel>_pmc_traffic.json (read by bench.py for roofline.traffic) and
 <out>/pmc_fetch_write_by_kernel.csv. Units and the gfx950 correction follow
@@ -63,8 +63,12 @@ def main() -> None:
     f_kib = ftot / nd
     w_kib = wtot / max(wd, 1)
     hbm = (f_kib * (2.0 if double_fetch else 1.0) + w_kib) * 1024.0
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from spatialcore_amd import _lib
+
     res = {
         "kernel": kernel,
+        "source_hash": _lib.source_hash(),
         "cells": cells,
         "perms": perms,
         "genes_per_gpu": genes,
