@@ -170,6 +170,20 @@ int sc_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, double *I_out
 int sc_lee(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, const int64_t *perm_offset,
            int64_t n_pairs, int64_t n_perm, double *L_out, int64_t *count_abs_ge_out,
            double *L_perm_out);
+/* sc_lee_seeded: the whole pair loop of lees_l (AC:1113-1155) in one call.  Every distinct gene is standardised once;
+ * the observed L[x][y] = sum_i z_x[i] (W z_y)[i] of all pairs is a dense contraction over the cells on the fp64 matrix
+ * cores (v_mfma_f64_16x16x4_f64 per 16 x 16 genes); each pair with two live genes then draws its OWN block of n_perm
+ * numpy-exact permutations, in pair order, from the one generator `state6` (pairs with a zero-variance gene draw
+ * nothing: L = 0, count = n_perm, AC:1129-1140), scored as sum_j (W^T z_x)[j] z_y[perm[j]] while the generator runs.
+ * count_abs_ge_out[q] = #{p : |L_perm| >= |L|}; L_perm_out (optional) is [n_pairs][n_perm].  state6 is advanced. */
+int sc_lee_seeded(sc_ctx *ctx, uint64_t *state6, const int32_t *pair_x, const int32_t *pair_y, int64_t n_pairs,
+                  int64_t n_perm, double *L_out, int64_t *count_abs_ge_out, double *L_perm_out);
+/* sc_lee_observed_f32: the reference's OWN observed L for a float32 matrix (AC:1118-1146, 307-315 computed in
+ * float32): numpy's pairwise float32 sums for mean / std / L, float32 standardisation, scipy's float32 csr_matvec for
+ * the lag -- the same roundings in the same order, evaluated in parallel (the summation tree depends on n alone).
+ * L32_out[q] is 0 for a pair with a zero-std gene; mean32_out / sd32_out (optional) are [n_pairs][2] (x, y). */
+int sc_lee_observed_f32(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, int64_t n_pairs, float *L32_out,
+                        float *mean32_out, float *sd32_out);
 
 /* ---- N1: Local Moran's I ---------------------------------------------------------------------
  * Replaces the batch body of local_morans_i (AC:845-896) for the loaded genes (= one batch), with the

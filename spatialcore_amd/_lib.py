@@ -55,6 +55,8 @@ SYMBOLS = {
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
+    "sc_lee_seeded": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
+    "sc_lee_observed_f32": [_P, _P, _P, c_int64, _P, _P, _P],
     "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
     "sc_local_moran_hist": [_P, _P],
     "sc_local_moran_classify": [_P, _P, _P, _P, c_float, _P, _P, _P],
@@ -369,6 +371,24 @@ class Context:
         Lp = np.empty((q, n_perm), dtype=np.float64) if return_perms else None
         _check(self._lib.sc_lee(self._h, _ptr(px), _ptr(py), _ptr(off), q, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
         return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
+
+    def lee_seeded(self, words: np.ndarray, pair_x, pair_y, n_perm: int, return_perms: bool = False):
+        """All pairs of a lees_l call: observed L (fp64 matrix cores) + per-pair permutation counts from the one
+        numpy-exact stream `words` (advanced in place), generator and scoring pipelined on the device."""
+        px, py = _c(pair_x, np.int32), _c(pair_y, np.int32)
+        q = px.size
+        L = np.empty(q, dtype=np.float64)
+        cnt = np.zeros(q, dtype=np.int64)
+        Lp = np.empty((q, n_perm), dtype=np.float64) if return_perms else None
+        _check(self._lib.sc_lee_seeded(self._h, _ptr(words), _ptr(px), _ptr(py), q, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
+        return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
+
+    def lee_observed_f32(self, pair_x, pair_y) -> np.ndarray:
+        """Observed L of each pair exactly as the reference's float32 arithmetic yields it (float32 matrices only)."""
+        px, py = _c(pair_x, np.int32), _c(pair_y, np.int32)
+        out = np.empty(px.size, dtype=np.float32)
+        _check(self._lib.sc_lee_observed_f32(self._h, _ptr(px), _ptr(py), px.size, _ptr(out), None, None))
+        return out
 
     # ---- N1 / N2 ----------------------------------------------------------------------------
     def local_moran(self, n_cells: int, n_perm: int, perm_row0: int = 0, fetch_counts: bool = True):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -127,6 +128,7 @@ struct sc_ctx {
     // ---- Moran / Lee work buffers ----
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
     DBuf lee_a, lee_b, lee_out, lee_pairs;
+    DBuf lee_U, lee_Zc, lee_Uc, lee_part, lee_obs, lee_cnt, lee_rowmap, lee_lperm;  // batched Lee (sc_lee.hip)
     bool lm_valid = false;   // z / lag / counts of the last sc_local_moran are still resident
     int64_t lm_perms = 0;
     DBuf np_cnt, np_comp, np_leaves, np_leafsum;  // numpy-order column sums: block counts, compacted values, leaf table, leaf sums
@@ -169,8 +171,13 @@ bool permgen_can_swap_inverse(int64_t n);
 int sc_perm_forward_ensure(sc_ctx *c);  // materialise c->perm from c->inv after a pipeline that only made the inverse
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);
 int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm);
+// generator / consumer pipeline (sc_moran.hip): table 0 = permutation rows, 1 = inverse rows only, 2 = both
+int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int table,
+                     const std::function<int()> &after_first, const std::function<int(int64_t, int64_t)> &score);
 
 int sc_timer_collect(sc_ctx *c);
+int sc_expr_zscores(sc_ctx *c);  // Z = (X - mean) / population sd per gene (0 for zero variance), variances in g_var
+int sc_lag_tiles(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const DBuf &data, const double *Z, double *out);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }

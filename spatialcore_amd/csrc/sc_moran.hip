@@ -8,9 +8,11 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <functional>
 #include <vector>
 
 #include "sc_ctx.h"
+#include "sc_pairwise.h"
 
 // ------------------------------------------------------------------------------------------------
 // expression upload
@@ -348,6 +350,22 @@ static int launch_lag(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const 
                        c->stream, indptr.as<int64_t>(), indices.as<int32_t>(), data.as<double>(), Z, out, n);
     SC_HIP(hipGetLastError());
     return SC_OK;
+}
+
+// helpers for the other translation units (sc_lee.hip): population-sd z-scores of the loaded genes in c->Z
+// (zero-variance genes -> 0, AC:1357-1359; c->g_var holds the variances), and the lag kernel on any CSR
+int sc_expr_zscores(sc_ctx *c)
+{
+    SC_TRY(expr_center(c));
+    hipLaunchKernelGGL(k_div_sd, dim3((unsigned)ceil_div64(c->e_n * SC_TILE, 256), (unsigned)c->e_tiles), dim3(256), 0,
+                       c->stream, c->Z.as<double>(), c->g_var.as<double>(), c->e_n);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+int sc_lag_tiles(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const DBuf &data, const double *Z, double *out)
+{
+    return launch_lag(c, indptr, indices, data, Z, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1045,15 +1063,21 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
 #define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
 #endif
 
-static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
-                             int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+// The generator / consumer pipeline shared by sc_moran_seeded and sc_lee_seeded: numpy-exact permutation rows
+// [0, n_perm) of length n are produced chunk by chunk on the generator's streams (stream2: rejection scan chain,
+// stream_pg: its preparation, stream_px: verification + expansion, stream3/4: Fisher-Yates swaps) while
+// `score(p0, p1)` consumes finished chunks on the context stream.  table: 0 = permutation rows (c->perm),
+// 1 = inverse rows only (c->inv; the same transpositions in ascending order), 2 = both (rows + k_invert_perm).
+// `after_first` runs on the host right after the first chunk of the generator has been enqueued (the generator is
+// the longest chain and depends on nothing else; everything host-blocking of the consumer's set-up goes here).
+int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int table,
+                     const std::function<int()> &after_first, const std::function<int(int64_t, int64_t)> &score)
 {
-    SC_REQUIRE(state6, SC_ERR_INVALID, "sc_moran_seeded: null state");
-    SC_TRY(moran_check(c, n_perm, I_out));
-    SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
-    const int64_t n = c->e_n;
+    SC_REQUIRE(state6, SC_ERR_INVALID, "permutation pipeline: null generator state");
+    SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "permutation pipeline: n_perm must be >= 1");
+    SC_REQUIRE(table == 0 || permgen_can_swap_inverse(n) || table == 2, SC_ERR_STATE, "inverse-only tables need a longer permutation");
     SC_TRY(sc_perm_alloc(c, n, n_perm));
-    if (!c->stream2) {  // the generator chain is the critical path: highest priority (plain stream if refused)
+    if (!c->stream2) {  // (SC_STREAM_PRIORITY=1: the r01 prioritised chain stream, for experiments; no gain measured in r02)
         int prio_lo = 0, prio_hi = 0;
         if (!getenv("SC_STREAM_PRIORITY") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
             hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
@@ -1065,11 +1089,10 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     if (!c->stream_px) SC_HIP(hipStreamCreateWithFlags(&c->stream_px, hipStreamNonBlocking));
     if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     if (!c->stream4) SC_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
-    // allocations first (hipMalloc synchronises the device), then the two streams run freely
-    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
-    SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
-    // chunk schedule: a short first chunk so that scoring starts early, PERM_CHUNK each in the middle, a short
-    // last chunk (the step ends with the swaps and the scoring of the last chunk after the scan is done)
+    // allocations first (hipMalloc synchronises the device), then the streams run freely
+    if (table >= 1) SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
+    // chunk schedule: a short first chunk so that the consumer starts early, PERM_CHUNK each in the middle, a short
+    // last chunk (the job ends with the swaps and the consumption of the last chunk after the scan is done)
     std::vector<int64_t> bounds;
     bounds.push_back(0);
     if (n_perm > 3 * PERM_CHUNK) {
@@ -1084,11 +1107,9 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         bounds.push_back(n_perm);
     }
     const int64_t chunks = (int64_t)bounds.size() - 1;
-    // stream2: scan(0) scan(1) ...   stream3/4: swaps(k) + inverse(k) after scan(k)   stream: score(k) after swaps(k)
+    // stream2: scan(0) scan(1) ...   stream3/4: swaps(k) (+ inverse(k)) after scan(k)   stream: score(k) after swaps(k)
     std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
     PermJob job;
-    // a float32 matrix is its own exact float32 copy: the scoring will gather through the inverse table only
-    const bool inverse_only = c->e_dtype == SC_F32 && c->source_bits_min <= 32 && permgen_can_swap_inverse(n);
     auto generate = [&](int64_t k) -> int {
         hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
         hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
@@ -1096,43 +1117,25 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
         SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
         SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
-        if (inverse_only) {
-            // the float32-source kernel only gathers through the inverse table, and the inverse of a Fisher-Yates
-            // result is the same transpositions in ascending order: no permutation table, no scatter pass
-            SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, true));
-        } else {
-            SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, false));
-            // inverse rows for the half-traffic kernel (harmless if the fp64 kernel ends up being used)
-            SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
-        }
+        SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, table == 1));
+        if (table == 2) SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
         SC_HIP(hipEventRecord(swapped, sw));
         return SC_OK;
     };
     int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
-    // The generator is the longest chain and depends on nothing else: its first chunk is enqueued first, then the
-    // observed statistic / lag / graph moments (host-blocking in places), then chunk k + 1 ahead of the scoring of
-    // chunk k, so that neither side waits for the host to enqueue the other (a chunk is some 250 API calls).
+    // chunk k + 1 of the generator is enqueued ahead of the consumption of chunk k, so that neither side waits for the
+    // host to enqueue the other (a chunk is some 250 API calls)
     if (rc == SC_OK) rc = generate(0);
-    if (rc == SC_OK) rc = moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK);
+    if (rc == SC_OK && after_first) rc = after_first();
     c->perm_bijective = true;  // device-generated rows are permutations by construction
-    const int bits = moran_source_bits(c);
-    // (a float32 matrix with NaNs fails the exactness test of its float32 copy: the fp64 kernel then needs the
-    // permutation rows themselves, made below from the inverse rows chunk by chunk)
-    const bool need_forward = inverse_only && bits > 32;
-    c->perm_forward_valid = !inverse_only || need_forward;
+    c->perm_forward_valid = table != 1;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
         if (k + 1 < chunks) rc = generate(k + 1);
         if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
-            sc_set_error("sc_moran_seeded: event plumbing failed");
+            sc_set_error("permutation pipeline: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK && need_forward) {
-            const int rows = (int)(bounds[(size_t)k + 1] - bounds[(size_t)k]);
-            hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((rows + 7) / 8) * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0,
-                               c->stream, c->inv.as<int32_t>() + bounds[(size_t)k] * c->p_stride,
-                               c->perm.as<int32_t>() + bounds[(size_t)k] * c->p_stride, c->e_n, c->p_stride, rows);
-        }
-        if (rc == SC_OK) rc = moran_perm_range(c, bounds[(size_t)k], bounds[(size_t)k + 1], bits, false);
+        if (rc == SC_OK) rc = score(bounds[(size_t)k], bounds[(size_t)k + 1]);
     }
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream3);
@@ -1146,7 +1149,42 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     if (rc != SC_OK) return rc;
     SC_TRY(permgen_finish(c, &job, state6));
     c->p_count = n_perm;
-    c->inv_rows_valid = n_perm;  // every chunk left its inverse rows (ascending swaps, or k_invert_perm)
+    c->inv_rows_valid = table >= 1 ? n_perm : 0;
+    return SC_OK;
+}
+
+static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
+                             int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+{
+    SC_REQUIRE(state6, SC_ERR_INVALID, "sc_moran_seeded: null state");
+    SC_TRY(moran_check(c, n_perm, I_out));
+    SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
+    const int64_t n = c->e_n;
+    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
+    // a float32 matrix is its own exact float32 copy: the scoring will gather through the inverse table only (the
+    // inverse of a Fisher-Yates result is the same transpositions in ascending order: no table, no scatter pass)
+    const bool inverse_only = c->e_dtype == SC_F32 && c->source_bits_min <= 32 && permgen_can_swap_inverse(n);
+    int bits = 64;
+    bool need_forward = false;
+    auto prepare = [&]() -> int {
+        SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
+        bits = moran_source_bits(c);
+        // (a float32 matrix with NaNs fails the exactness test of its narrow copy: the fp64 kernel then needs the
+        // permutation rows themselves, made below from the inverse rows chunk by chunk)
+        need_forward = inverse_only && bits > 32;
+        return SC_OK;
+    };
+    auto score = [&](int64_t p0, int64_t p1) -> int {
+        if (need_forward) {
+            const int rows = (int)(p1 - p0);
+            hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((rows + 7) / 8) * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0,
+                               c->stream, c->inv.as<int32_t>() + p0 * c->p_stride, c->perm.as<int32_t>() + p0 * c->p_stride,
+                               c->e_n, c->p_stride, rows);
+        }
+        return moran_perm_range(c, p0, p1, bits, false);
+    };
+    SC_TRY(sc_perm_pipeline(c, state6, n, n_perm, inverse_only ? 1 : 2, prepare, score));
+    if (need_forward) c->perm_forward_valid = true;
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
@@ -1452,37 +1490,6 @@ __global__ __launch_bounds__(256) void k_npc_scatter(const double *__restrict__ 
             base[g] += (uint32_t)__popcll(bal);
         }
     }
-}
-
-// numpy's pairwise recursion over `len` elements: a leaf is <= 128 elements, above that the split is len / 2
-// rounded down to a multiple of 8.  Visits the leaves in order; at a leaf `leaf(start, len)` supplies the value.
-template <typename T, typename Leaf>
-__device__ T pw_walk(uint32_t n, Leaf leaf)
-{
-    uint32_t f_len[34], f_start[34];
-    T f_left[34];
-    unsigned char f_state[34];
-    int sp = 0;
-    T ret = (T)0;
-    f_len[0] = n; f_start[0] = 0; f_state[0] = 0; sp = 1;
-    while (sp > 0) {
-        const int k = sp - 1;
-        const uint32_t len = f_len[k];
-        uint32_t n2 = len / 2; n2 -= n2 % 8;
-        if (f_state[k] == 0) {
-            if (len <= 128) { ret = leaf(f_start[k], len); --sp; continue; }
-            f_state[k] = 1;
-            f_len[sp] = n2; f_start[sp] = f_start[k]; f_state[sp] = 0; ++sp;
-        } else if (f_state[k] == 1) {
-            f_left[k] = ret;
-            f_state[k] = 2;
-            f_len[sp] = len - n2; f_start[sp] = f_start[k] + n2; f_state[sp] = 0; ++sp;
-        } else {
-            ret = f_left[k] + ret;
-            --sp;
-        }
-    }
-    return ret;
 }
 
 // leaves[gene][i] = (start, len) of the i-th leaf of the recursion over elements 1 .. nnz-1; nleaves[gene]

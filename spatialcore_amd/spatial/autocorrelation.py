@@ -92,6 +92,23 @@ def _knn_weights_f32(ctx, coords: np.ndarray, n_neighbors: int, include_self: bo
     return w
 
 
+def _radius_weights(ctx, coords: np.ndarray, radius: float, float32_weights: bool):
+    """EXTENSION (BASELINE configs[2]; the reference's Moran / Lee functions only take ``n_neighbors``, AC:342-347):
+    the closed-ball radius graph of ``compute_neighborhood_profile`` (NB:241-251: d <= radius, self excluded) as the
+    active graph, row-normalised like the kNN weights (1 / degree; float32-valued for the in-repo float32 paths,
+    fp64 for the squidpy-style Moran path).  Cells without a neighbour keep an empty row (lag 0).
+    Returns (indptr, indices, data) as uploaded."""
+    if radius is None or not radius > 0:
+        raise ValueError(f"radius must be > 0, got {radius}")
+    indptr, indices = ctx.radius_graph(coords, float(radius))
+    deg = np.diff(indptr)
+    with np.errstate(divide="ignore"):
+        w = (np.float32(1.0) / deg.astype(np.float32)).astype(np.float64) if float32_weights else 1.0 / deg
+    data = np.repeat(w, deg)
+    ctx.set_graph_csr(indptr, indices, data, coords.shape[0])
+    return indptr, indices, data
+
+
 # =============================================================================================
 # FDR / quadrants (AC:132-265) -- O(n) bookkeeping on per-cell outputs
 # =============================================================================================
@@ -258,6 +275,7 @@ def morans_i(
     use_existing_graph: bool = False,
     *,
     device: int = 0,
+    radius: Optional[float] = None,
 ):
     """Global Moran's I with permutation p-values (AC:421-648).
 
@@ -270,6 +288,9 @@ def morans_i(
     the GPU: exact kNN, row-normalised lag, and ``P`` permutations drawn from the numpy-exact
     ``default_rng(seed).permutation(n)`` stream, each scored as
     ``sum_i z_i * lag[perm[i]]`` (identical to scoring the row-permuted graph).
+
+    Extension (keyword-only, default keeps the reference's behaviour): ``radius`` -- use the closed-ball radius graph
+    (row-normalised) instead of the kNN graph; ``n_neighbors`` is then ignored.
     """
     start_time = time.time()
     coords = _require_spatial(adata, spatial_key)
@@ -294,6 +315,13 @@ def morans_i(
     if use_existing_graph and "spatial_connectivities" in adata.obsp:
         logger.info("Using existing spatial connectivity graph (use_existing_graph=True)")
         _upload_existing_graph(ctx, adata.obsp["spatial_connectivities"])
+    elif radius is not None:
+        logger.debug(f"Building spatial radius graph (r={radius})")
+        indptr, indices, data = _radius_weights(ctx, coords, radius, float32_weights=False)
+        adata.obsp["spatial_connectivities"] = csr_matrix((np.ones(indices.size), indices, indptr), shape=(n_cells, n_cells))
+        adata.uns["spatial_neighbors"] = {"connectivities_key": "spatial_connectivities", "distances_key": None,
+                                          "params": {"n_neighbors": None, "coord_type": "generic", "radius": float(radius),
+                                                     "transform": None}}
     else:
         logger.debug(f"Building spatial neighbors graph (k={n_neighbors})")
         _squidpy_neighbors(ctx, adata, coords, n_neighbors, spatial_key)
@@ -343,39 +371,6 @@ def _normalize_pairs(gene_pairs):
     return list(gene_pairs), single
 
 
-# device bytes allowed for one block of Lee permutations
-_LEE_PERM_BUDGET = 8 << 30
-
-
-def _lee_run(ctx, n_cells: int, pair_slots: np.ndarray, var: np.ndarray, n_permutations: int, seed_rng,
-             return_perms: bool = False):
-    """Global L + permutation counts for (x, y) slot pairs, drawing a fresh block of P permutations
-    per non-degenerate pair from ONE stream, in pair order (AC:1109-1148).  ``seed_rng`` is the 6-word
-    stream state, advanced in place."""
-    n_pairs = pair_slots.shape[0]
-    L = np.zeros(n_pairs)
-    cnt = np.zeros(n_pairs, dtype=np.int64)
-    Lp = np.zeros((n_pairs, n_permutations)) if return_perms else None
-    degenerate = ~((var[pair_slots[:, 0]] > 0) & (var[pair_slots[:, 1]] > 0))
-    per_block = max(1, int(_LEE_PERM_BUDGET // max(1, 4 * n_cells * max(n_permutations, 1))))
-    q = 0
-    while q < n_pairs:
-        q1 = min(n_pairs, q + per_block)
-        sel = np.arange(q, q1)
-        off = np.full(sel.size, -1, dtype=np.int64)
-        live = ~degenerate[sel]
-        off[live] = np.arange(int(live.sum())) * n_permutations
-        if n_permutations > 0 and live.any():
-            ctx.generate_permutations(seed_rng, n_cells, int(live.sum()) * n_permutations)
-        r = ctx.lee(pair_slots[sel, 0], pair_slots[sel, 1], off, n_permutations, return_perms=return_perms)
-        L[sel] = r["L"]
-        cnt[sel] = r["count_abs_ge"]
-        if return_perms:
-            Lp[sel] = r["L_perm"]
-        q = q1
-    return L, cnt, degenerate, Lp
-
-
 def lees_l(
     adata,
     gene_pairs: Union[Tuple[str, str], List[Tuple[str, str]]],
@@ -386,6 +381,7 @@ def lees_l(
     seed: int = 0,
     *,
     device: int = 0,
+    radius: Optional[float] = None,
 ) -> Union[dict, List[dict]]:
     """Global Lee's L bivariate spatial association with permutation p-values (AC:991-1163).
 
@@ -393,7 +389,10 @@ def lees_l(
     ``L = sum_i z_x[i] * (W z_y)[i]`` on population-std z-scores; the permutation loop shuffles
     ``z_y`` with the numpy-exact stream (one generator for all pairs, pairs with a zero-variance
     gene draw nothing) and is evaluated on the GPU as ``sum_j (W^T z_x)[j] * z_y[perm[j]]``.
-    Arithmetic is fp64 (the reference inherits X's dtype).
+    The whole pair loop is ONE device call (``sc_lee_seeded``): all observed statistics as a dense
+    contraction on the fp64 matrix cores, permutation blocks generated and scored in a pipeline.
+    Permutation statistics are fp64; for a float32 matrix the reported ``L`` is the reference's own float32 result
+    (numpy's pairwise float32 sums and scipy's float32 mat-vec reproduced on the device).
     """
     start_time = time.time()
     coords = _require_spatial(adata, spatial_key)
@@ -408,14 +407,26 @@ def lees_l(
                 f"k={n_neighbors}, permutations={n_permutations}")
 
     ctx = _lib.default_context(device)
-    _knn_weights_f32(ctx, coords, n_neighbors)
+    if radius is not None:   # extension: radius graph instead of kNN (see _radius_weights)
+        _radius_weights(ctx, coords, radius, float32_weights=True)
+    else:
+        _knn_weights_f32(ctx, coords, n_neighbors)
     flat = [g for pair in gene_pairs for g in pair]
     cols, where = _unique_columns(adata, flat)
     ctx.set_expression(_expression(adata, layer), cols)
     _, var = ctx.expr_stats()
     pair_slots = where.reshape(-1, 2)
+    degenerate = ~((var[pair_slots[:, 0]] > 0) & (var[pair_slots[:, 1]] > 0))
+    # one device call for the whole pair loop: observed L of every pair on the fp64 matrix cores, then a fresh block of
+    # P numpy-exact permutations per live pair, in pair order, from ONE stream (AC:1109-1148)
     words = _lib.rng_state_words(np.random.default_rng(seed))
-    L, cnt, degenerate, _ = _lee_run(ctx, n_cells, pair_slots, var, n_permutations, words)
+    out = ctx.lee_seeded(words, pair_slots[:, 0], pair_slots[:, 1], n_permutations)
+    L, cnt = out["L"], out["count_abs_ge"]
+    X_in = _expression(adata, layer)
+    if getattr(X_in, "dtype", None) == np.float32:
+        # the reference computes a float32 matrix in float32 (AC:1118-1146); hand back ITS number: same roundings,
+        # same (numpy pairwise) summation order -- an fp64 L differs from it by the float32 noise, ~1e-5 relative
+        L = ctx.lee_observed_f32(pair_slots[:, 0], pair_slots[:, 1]).astype(np.float64)
 
     results = []
     for q, (gene_x, gene_y) in enumerate(gene_pairs):

@@ -514,6 +514,91 @@ def test_lee_vs_reference_golden(ctx, oracle):
         np.testing.assert_array_equal(p, g[f"c{ci}_p"])
 
 
+def test_lee_seeded_batch_vs_pairwise_path_and_golden(ctx, oracle):
+    """sc_lee_seeded (one call: MFMA observed statistics + pipelined per-pair permutation blocks) against the
+    reference's golden output and against the per-pair path (sc_perm_generate + sc_lee) on the same stream."""
+    from spatialcore_amd._lib import rng_state_words
+
+    g = load_golden("ref_lees_l.npz")
+    for ci in range(int(g["n_cases"])):
+        coords, X = g[f"c{ci}_coords"], g[f"c{ci}_X"]
+        k, P, seed = int(g[f"c{ci}_k"]), int(g[f"c{ci}_P"]), int(g[f"c{ci}_seed"])
+        pairs = g[f"c{ci}_pairs"]
+        n = X.shape[0]
+        ctx.knn(coords, k, fetch=False)
+        ctx.graph_from_knn(float(np.float32(1.0) / np.float32(k)))
+        ctx.set_expression(X, np.arange(X.shape[1]))
+        _, var = ctx.expr_stats()
+        live = np.array([var[a] > 0 and var[b] > 0 for a, b in pairs])
+        w = rng_state_words(np.random.default_rng(seed))
+        out = ctx.lee_seeded(w, pairs[:, 0], pairs[:, 1], P, return_perms=True)
+        tol = 1e-9 if X.dtype == np.float64 else 2e-5
+        np.testing.assert_allclose(out["L"], g[f"c{ci}_L"], rtol=tol, atol=tol)
+        p = np.where(live, (out["count_abs_ge"] + 1) / (P + 1), 1.0) if P > 0 else np.ones(len(pairs))
+        np.testing.assert_array_equal(p, g[f"c{ci}_p"])
+        # the per-pair path on the same stream: same permutation statistics to summation order, same state afterwards
+        w2 = rng_state_words(np.random.default_rng(seed))
+        off = np.where(live, np.cumsum(live) - 1, -1) * P
+        off[~live] = -1
+        if P > 0 and live.any():
+            ctx.generate_permutations(w2, n, int(live.sum()) * P)
+            np.testing.assert_array_equal(w, w2)
+        ref = ctx.lee(pairs[:, 0], pairs[:, 1], off, P, return_perms=True)
+        np.testing.assert_allclose(out["L"], ref["L"], rtol=1e-12, atol=1e-12)
+        if P > 0:
+            np.testing.assert_allclose(out["L_perm"], ref["L_perm"], rtol=1e-9, atol=1e-10)
+            np.testing.assert_array_equal(out["count_abs_ge"][live], ref["count_abs_ge"][live])
+            np.testing.assert_array_equal(out["count_abs_ge"][~live], P)
+
+
+def test_lee_seeded_dense_pair_grid_mfma(ctx, oracle):
+    """A 37 x 21 grid of pairs over 58 genes (several 16-gene tiles per side, ragged last tiles): the fp64 MFMA
+    contraction of the observed statistics against plain dot products of the oracle's z-scores and lags, P = 0."""
+    n, G = 6000, 58
+    coords, X = synth(n, G, 21, dtype=np.float64, sparse_x=False)
+    X[:, 5] = 3.0                                              # one zero-variance gene on the x side
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(float(np.float32(1.0) / np.float32(6)))
+    ctx.set_expression(X, np.arange(G))
+    px, py = np.meshgrid(np.arange(37), np.arange(37, 58), indexing="ij")
+    out = ctx.lee_seeded(None, px.ravel(), py.ravel(), 0)
+    W = oracle.reference_weights(coords, 6).astype(np.float64)
+    sd = X.std(axis=0)
+    Z = np.where(sd > 0, (X - X.mean(axis=0)) / np.where(sd > 0, sd, 1), 0.0)
+    want = Z[:, :37].T @ (W @ Z[:, 37:])
+    want[5, :] = 0.0
+    np.testing.assert_allclose(out["L"].reshape(37, 21), want, rtol=1e-10, atol=1e-9)
+    assert (out["count_abs_ge"] == 0).all()
+
+
+@pytest.mark.parametrize("n", [1200, 8192, 8200, 70001])
+def test_lee_observed_float32_is_numpys_own_number(ctx, oracle, n):
+    """For a float32 matrix the reference's L is numpy / scipy float32 arithmetic (AC:1118-1146, 307-315).  The device
+    evaluates the same summation tree with the same roundings (chunks of 8192, pairwise inside): bit-for-bit the
+    numbers numpy itself produces here for the restated formula, across the chunk boundary cases."""
+    coords, X = synth(n, 6, 40 + n % 7, dtype=np.float32, sparse_x=False)
+    X[:, 4] = 2.0                                                   # zero float32 std
+    W = oracle.reference_weights(coords, 6)                         # float32 CSR, as build_spatial_weights returns
+    pairs = np.array([[0, 1], [2, 3], [1, 0], [4, 2], [5, 5]])
+    want = []
+    for a, b in pairs:
+        x, y = X[:, a], X[:, b]
+        if x.std() == 0 or y.std() == 0:
+            want.append(0.0)
+            continue
+        zx, zy = (x - x.mean()) / x.std(), (y - y.mean()) / y.std()
+        want.append(float((zx * (W @ zy)).sum()))
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(float(np.float32(1.0) / np.float32(6)))
+    ctx.set_expression(X, np.arange(6))
+    got = ctx.lee_observed_f32(pairs[:, 0], pairs[:, 1])
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got.astype(np.float64), np.array(want))
+    ctx.set_expression(X.astype(np.float64), np.arange(6))
+    with pytest.raises(Exception, match="not float32"):
+        ctx.lee_observed_f32(pairs[:, 0], pairs[:, 1])
+
+
 def test_profile_counts_golden(ctx):
     g = load_golden("ref_profile.npz")
     coords, labels = g["coords"], g["labels"]
