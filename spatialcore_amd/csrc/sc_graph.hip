@@ -1085,6 +1085,8 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
     SC_REQUIRE(c->g_n > 0 && n == c->g_n, SC_ERR_STATE, "sc_enrichment_counts: graph missing or size mismatch");
     SC_REQUIRE(n_types >= 1 && n_types <= 96, SC_ERR_INVALID, "sc_enrichment_counts: n_types must be 1..96");
     SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_enrichment_counts: negative size");
+    SC_REQUIRE(n_perm + 1 <= 65535, SC_ERR_INVALID, "sc_enrichment_counts: at most 65534 permutations per call (got %lld); "
+               "call it per batch of the table", (long long)n_perm);
     if (n_perm > 0)
         SC_REQUIRE(c->p_n == n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
                    "sc_enrichment_counts: needs permutation rows [%lld, %lld)", (long long)perm_row0,
