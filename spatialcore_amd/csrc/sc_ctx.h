@@ -96,6 +96,10 @@ struct sc_ctx {
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
     bool s0_valid = false;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // graph moments (valid with s0_valid)
+    // a processing order with spatial locality for kernels that read neighbours' rows (local Moran): the bin-sorted
+    // order of the points the graph was built from (identity for a graph of unknown geometry).  Results never depend on it.
+    DBuf g_order, g_rank, g_indices_r, g_w32, g_erow_r;   // [n] sorted position -> cell, [n] cell -> position, [nnz] rank of the column, float weights, [nnz] rank of the row
+    bool g_order_captured = false, g_order_ready = false;
 
     // ---- expression tiles ----
     int64_t e_n = 0, e_genes = 0, e_tiles = 0;
@@ -129,8 +133,10 @@ struct sc_ctx {
     DBuf partial, sims, counts, sim_sum, sim_sumsq;
     DBuf lee_a, lee_b, lee_out, lee_pairs;
     DBuf lee_U, lee_Zc, lee_Uc, lee_part, lee_obs, lee_cnt, lee_rowmap, lee_lperm;  // batched Lee (sc_lee.hip)
+    bool lm_direct = false;  // local Moran per-cell counts: the r01 one-kernel form instead of the two-phase sorted form (A/B)
     bool lm_valid = false;   // z / lag / counts of the last sc_local_moran are still resident
     int64_t lm_perms = 0;
+    DBuf lm_ys;              // local Moran: the permuted z rows of a batch of permutations, in the graph's processing order
     DBuf np_cnt, np_comp, np_leaves, np_leafsum;  // numpy-order column sums: block counts, compacted values, leaf table, leaf sums
 };
 
@@ -185,6 +191,8 @@ static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b)
 // ---- implemented across translation units ----
 int sc_graph_ensure_transpose(sc_ctx *c);
 int sc_graph_ensure_s0(sc_ctx *c);
+int sc_graph_capture_order(sc_ctx *c, int64_t n);  // called by the graph setters
+int sc_graph_ensure_order(sc_ctx *c);           // rank / relabelled columns / float weights, built on first use
 int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm);
 void sc_launch_spmv_vec(sc_ctx *c, const int64_t *indptr, const int32_t *indices, const double *w,
                         const double *x, double *y, int64_t n);

@@ -400,6 +400,75 @@ __global__ __launch_bounds__(256) void k_check_csr(const long long *__restrict__
     if (bad) atomicOr(flag, bad);
 }
 
+// ---- processing order with spatial locality (see sc_ctx.h) ----
+__global__ __launch_bounds__(256) void k_iota32(int32_t *__restrict__ a, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_rank_of(const int32_t *__restrict__ order, int64_t n, int32_t *__restrict__ rank)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) rank[order[r]] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(256) void k_relabel_edges(const int32_t *__restrict__ indices, const double *__restrict__ w,
+                                                       const int32_t *__restrict__ rank, int64_t nnz,
+                                                       int32_t *__restrict__ indices_r, float *__restrict__ w32)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    indices_r[e] = rank[indices[e]];
+    w32[e] = (float)w[e];
+}
+
+__global__ __launch_bounds__(256) void k_edge_rows(const long long *__restrict__ indptr, const int32_t *__restrict__ rank,
+                                                   int64_t n, int32_t *__restrict__ erow_r)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = rank[i];
+    for (long long e = indptr[i]; e < indptr[i + 1]; ++e) erow_r[e] = r;
+}
+
+// The graph setters call this: if the points of the last neighbour search are the graph's cells (same count), their
+// bin-sorted order is kept with the graph; otherwise the identity.  A wrong guess costs speed, never correctness.
+int sc_graph_capture_order(sc_ctx *c, int64_t n)
+{
+    c->g_order_ready = false;
+    SC_TRY(c->g_order.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
+    if (c->pts_n == n && c->sid.p)
+        SC_HIP(hipMemcpyAsync(c->g_order.p, c->sid.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    else
+        hipLaunchKernelGGL(k_iota32, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->g_order.as<int32_t>(), n);
+    SC_HIP(hipGetLastError());
+    c->g_order_captured = true;
+    return SC_OK;
+}
+
+int sc_graph_ensure_order(sc_ctx *c)
+{
+    if (c->g_order_ready) return SC_OK;
+    const int64_t n = c->g_n, nnz = c->g_nnz;
+    SC_REQUIRE(n > 0 && c->g_order_captured, SC_ERR_STATE, "no graph set");
+    SC_TRY(c->g_rank.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
+    SC_TRY(c->g_indices_r.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    SC_TRY(c->g_w32.ensure(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    SC_TRY(c->g_erow_r.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
+    hipLaunchKernelGGL(k_rank_of, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->g_order.as<int32_t>(), n,
+                       c->g_rank.as<int32_t>());
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_relabel_edges, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, c->stream,
+                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), c->g_rank.as<int32_t>(), nnz,
+                           c->g_indices_r.as<int32_t>(), c->g_w32.as<float>());
+    hipLaunchKernelGGL(k_edge_rows, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                       c->g_rank.as<int32_t>(), n, c->g_erow_r.as<int32_t>());
+    SC_HIP(hipGetLastError());
+    c->g_order_ready = true;
+    return SC_OK;
+}
+
 extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t *indices, const double *data,
                                 int64_t n, int64_t nnz)
 {
@@ -432,6 +501,7 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     SC_REQUIRE(!(flag & 1), SC_ERR_INVALID, "sc_graph_set_csr: column index out of range");
     SC_REQUIRE(!(flag & 2), SC_ERR_INVALID,
                "sc_graph_set_csr: rows must have strictly ascending column indices (sort_indices/sum_duplicates)");
+    SC_TRY(sc_graph_capture_order(c, n));
     c->g_n = n;
     c->g_nnz = nnz;
     return SC_OK;
@@ -472,6 +542,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
                        c->knn_idx.as<int32_t>(), n, c->knn_k, weight, c->g_indptr.as<long long>(),
                        c->g_indices.as<int32_t>(), c->g_data.as<double>());
     SC_HIP(hipGetLastError());
+    SC_TRY(sc_graph_capture_order(c, n));
     SC_HIP(hipStreamSynchronize(c->stream));
     c->g_n = n;
     c->g_nnz = nnz;
@@ -1046,34 +1117,57 @@ extern "C" int sc_pair_table_2d(sc_ctx *c, const double *xy_a, const int64_t *a_
 // range; the T x T histogram lives in LDS (integer atomics: deterministic), then is added to global.
 // ------------------------------------------------------------------------------------------------
 
-#define ENR_CELLS_PER_BLOCK 16384
+#define ENR_EDGES_PER_BLOCK 65536
 
-__global__ __launch_bounds__(256) void k_enrich(const long long *__restrict__ indptr,
-                                                const int32_t *__restrict__ indices,
-                                                const unsigned char *__restrict__ lab,
-                                                const int32_t *__restrict__ perm, int64_t pstride, int n_perm,
-                                                int64_t n, int n_types, unsigned long long *__restrict__ counts)
+// labp[p][r] = lab[perm_p[order[r]]] (p == n_perm: the identity, i.e. the observed labels): the permuted label of
+// the cell at position r of the graph's spatially sorted processing order.  The edge kernel then needs ONE byte per
+// edge end from an n-byte array (instead of a 4-byte index gather followed by a byte gather), and the two ends of an
+// edge -- spatial neighbours -- sit at nearby positions: the row's k + 1 bytes come from one or two cache lines.
+__global__ __launch_bounds__(256) void k_enrich_relabel(const unsigned char *__restrict__ lab,
+                                                        const int32_t *__restrict__ order,
+                                                        const int32_t *__restrict__ perm, int64_t pstride, int n_perm,
+                                                        int64_t n, int64_t lstride, unsigned char *__restrict__ labp)
+{
+    const int p = blockIdx.y;
+    const int32_t *prow = p < n_perm ? perm + (int64_t)p * pstride : nullptr;
+    const int64_t r0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (r0 >= n) return;
+    unsigned char *dst = labp + (int64_t)p * lstride;
+    uint32_t v = 0;
+    for (int k = 0; k < 4 && r0 + k < n; ++k) {
+        const int32_t cell = order[r0 + k];
+        v |= (uint32_t)lab[prow ? prow[cell] : cell] << (8 * k);
+    }
+    if (r0 + 4 <= n) *reinterpret_cast<uint32_t *>(dst + r0) = v;
+    else for (int k = 0; r0 + k < n; ++k) dst[r0 + k] = (unsigned char)(v >> (8 * k));
+}
+
+// counts[p][a][b] += #{edges of the block : label(row) = a, label(column) = b}.  One thread per EDGE (coalesced reads of
+// the two relabelled end positions; consecutive workgroups are the permutations of ONE edge block, which L2 serves),
+// `copies` private T x T histograms per workgroup (lane l adds into copy l % copies, copy stride odd: with ~20 skewed
+// cell types most of a wavefront's 64 LDS atomics would otherwise hit a handful of addresses and banks and serialise).
+__global__ __launch_bounds__(256) void k_enrich(const int32_t *__restrict__ erow_r, const int32_t *__restrict__ ecol_r,
+                                                int64_t nnz, const unsigned char *__restrict__ labp, int64_t lstride,
+                                                int n_types, int copies, int cstride, unsigned long long *__restrict__ counts)
 {
     extern __shared__ unsigned int hist[];
-    const int p = blockIdx.y;
+    const int p = blockIdx.x;
     const int tt = n_types * n_types;
-    for (int k = threadIdx.x; k < tt; k += 256) hist[k] = 0;
+    for (int k = threadIdx.x; k < cstride * copies; k += 256) hist[k] = 0;
     __syncthreads();
-    const int32_t *prow = p < n_perm ? perm + (int64_t)p * pstride : nullptr;
-    const int64_t i0 = (int64_t)blockIdx.x * ENR_CELLS_PER_BLOCK;
-    const int64_t i1 = i0 + ENR_CELLS_PER_BLOCK < n ? i0 + ENR_CELLS_PER_BLOCK : n;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const int a = lab[prow ? prow[i] : (int32_t)i];
-        for (long long e = indptr[i]; e < indptr[i + 1]; ++e) {
-            const int32_t j = indices[e];
-            const int b = lab[prow ? prow[j] : j];
-            atomicAdd(&hist[a * n_types + b], 1u);
-        }
-    }
+    const unsigned char *lp = labp + (int64_t)p * lstride;
+    unsigned int *mine = hist + (threadIdx.x & (copies - 1)) * cstride;
+    const int64_t e0 = (int64_t)blockIdx.y * ENR_EDGES_PER_BLOCK;
+    const int64_t e1 = e0 + ENR_EDGES_PER_BLOCK < nnz ? e0 + ENR_EDGES_PER_BLOCK : nnz;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
+        atomicAdd(&mine[(int)lp[erow_r[e]] * n_types + lp[ecol_r[e]]], 1u);
     __syncthreads();
     unsigned long long *out = counts + (int64_t)p * tt;
-    for (int k = threadIdx.x; k < tt; k += 256)
-        if (hist[k]) atomicAdd(&out[k], (unsigned long long)hist[k]);
+    for (int k = threadIdx.x; k < tt; k += 256) {
+        unsigned int v = 0;
+        for (int c = 0; c < copies; ++c) v += hist[c * cstride + k];
+        if (v) atomicAdd(&out[k], (unsigned long long)v);
+    }
 }
 
 extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n, int32_t n_types, int64_t n_perm,
@@ -1085,8 +1179,9 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
     SC_REQUIRE(c->g_n > 0 && n == c->g_n, SC_ERR_STATE, "sc_enrichment_counts: graph missing or size mismatch");
     SC_REQUIRE(n_types >= 1 && n_types <= 96, SC_ERR_INVALID, "sc_enrichment_counts: n_types must be 1..96");
     SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_enrichment_counts: negative size");
-    SC_REQUIRE(n_perm + 1 <= 65535, SC_ERR_INVALID, "sc_enrichment_counts: at most 65534 permutations per call (got %lld); "
-               "call it per batch of the table", (long long)n_perm);
+    SC_REQUIRE(n_perm + 1 <= 65535 && ceil_div64(c->g_nnz, ENR_EDGES_PER_BLOCK) <= 65535, SC_ERR_INVALID,
+               "sc_enrichment_counts: at most 65534 permutations per call (got %lld) and 4.2e9 edges; call it per batch of the table",
+               (long long)n_perm);
     if (n_perm > 0)
         SC_REQUIRE(c->p_n == n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
                    "sc_enrichment_counts: needs permutation rows [%lld, %lld)", (long long)perm_row0,
@@ -1099,15 +1194,26 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
     }
     const size_t tt = (size_t)n_types * n_types;
     const size_t out_bytes = sizeof(unsigned long long) * tt * (size_t)(n_perm + 1);
+    const int64_t lstride = align_up64(n, 16);
     SC_TRY(c->lee_pairs.ensure((size_t)n + 16, &c->mem));
     SC_TRY(c->lee_b.ensure(out_bytes, &c->mem));
+    SC_TRY(c->lee_a.ensure((size_t)lstride * (size_t)(n_perm + 1), &c->mem));   // permuted label vectors
     SC_HIP(hipMemcpyAsync(c->lee_pairs.p, lab8.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
     SC_HIP(hipMemsetAsync(c->lee_b.p, 0, out_bytes, c->stream));
-    dim3 grid((unsigned)ceil_div64(n, ENR_CELLS_PER_BLOCK), (unsigned)(n_perm + 1));
-    hipLaunchKernelGGL(k_enrich, grid, dim3(256), sizeof(unsigned int) * tt, c->stream, c->g_indptr.as<long long>(),
-                       c->g_indices.as<int32_t>(), c->lee_pairs.as<unsigned char>(),
-                       c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, n, (int)n_types,
-                       c->lee_b.as<unsigned long long>());
+    SC_TRY(sc_graph_ensure_order(c));
+    hipLaunchKernelGGL(k_enrich_relabel, dim3((unsigned)ceil_div64(n, 1024), (unsigned)(n_perm + 1)), dim3(256), 0, c->stream,
+                       c->lee_pairs.as<unsigned char>(), c->g_order.as<int32_t>(),
+                       c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, n, lstride,
+                       c->lee_a.as<unsigned char>());
+    if (c->g_nnz > 0) {
+        int copies = 16;
+        const int cstride = (int)tt | 1;   // odd: copy c starts at a different LDS bank
+        while (copies > 1 && (size_t)copies * cstride > 12288) copies >>= 1;   // <= 48 KB of LDS per workgroup
+        dim3 grid((unsigned)(n_perm + 1), (unsigned)ceil_div64(c->g_nnz, ENR_EDGES_PER_BLOCK));
+        hipLaunchKernelGGL(k_enrich, grid, dim3(256), sizeof(unsigned int) * cstride * copies, c->stream,
+                           c->g_erow_r.as<int32_t>(), c->g_indices_r.as<int32_t>(), c->g_nnz, c->lee_a.as<unsigned char>(),
+                           lstride, (int)n_types, copies, cstride, c->lee_b.as<unsigned long long>());
+    }
     SC_HIP(hipGetLastError());
     SC_HIP(hipMemcpyAsync(counts_out, c->lee_b.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));

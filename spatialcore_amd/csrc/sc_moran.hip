@@ -1649,6 +1649,65 @@ __global__ __launch_bounds__(256) void k_lm_perm_count(const long long *__restri
     reinterpret_cast<int4 *>(count)[o] = make_int4(cx, cy, cz, cw);
 }
 
+// ---- the same count in two phases per batch of permutations, in the graph's processing order (r02) ----
+// k_lm_perm_count above reads, per permutation and cell, k + 1 permutation indices and k + 1 random 64-byte z rows
+// per gene tile.  Per cell i the permuted vector y = z[perm] is all that matters: I_perm[i] = y[i] * sum_e w_e y[col_e].
+// Phase A materialises y once per (permutation, tile) -- ONE random row per cell -- at the cell's position r in a
+// spatially sorted order (Ys[r] = Z[perm[order[r]]]); phase B is then a LOCAL sparse product: the neighbours of a cell
+// sit at nearby positions, their rows are served by L1 / L2.  The edges of a row keep their ascending-column order,
+// so every sum is the reference's row-sequential float32 sum, bit for bit.
+#define LM_PERM_BATCH 8
+
+// Ys[p][tile][r][16] = Z32[tile][perm_p[order[r]]][16]      thread = (r, q), grid.y = tile, grid.z = permutation of the batch
+__global__ __launch_bounds__(256) void k_lm_gather_sorted(const float *__restrict__ Z32, const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ perm, int64_t pstride, int64_t n,
+                                                          int64_t tiles, float *__restrict__ Ys)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 2;
+    const int q = (int)(t & 3);
+    if (r >= n) return;
+    const int32_t src = perm[(int64_t)blockIdx.z * pstride + order[r]];
+    const float4 v = reinterpret_cast<const float4 *>(Z32 + (int64_t)blockIdx.y * n * SC_TILE)[(int64_t)src * 4 + q];
+    reinterpret_cast<float4 *>(Ys + ((int64_t)blockIdx.z * tiles + blockIdx.y) * n * SC_TILE)[r * 4 + q] = v;
+}
+
+// count[tile][cell][16] += #{p in batch : |y[r] * sum_e w_e y[rank(col_e)]| >= |I[cell]|},  cell = order[r]
+__global__ __launch_bounds__(256) void k_lm_count_sorted(const long long *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices_r,
+                                                         const float *__restrict__ w32, const int32_t *__restrict__ order,
+                                                         const float *__restrict__ Ys, const float *__restrict__ I32,
+                                                         int n_batch, int64_t tiles, int32_t *__restrict__ count, int64_t n,
+                                                         int first)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 2;
+    const int q = (int)(t & 3);
+    if (r >= n) return;
+    const int64_t i = order[r];
+    const int64_t o = (int64_t)blockIdx.y * n * 4 + i * 4 + q;
+    const float4 obs = reinterpret_cast<const float4 *>(I32)[o];
+    const float ax = fabsf(obs.x), ay = fabsf(obs.y), az = fabsf(obs.z), aw = fabsf(obs.w);
+    const long long e0 = indptr[i], e1 = indptr[i + 1];
+    int cx = 0, cy = 0, cz = 0, cw = 0;
+    for (int p = 0; p < n_batch; ++p) {
+        const float4 *Y = reinterpret_cast<const float4 *>(Ys + ((int64_t)p * tiles + blockIdx.y) * n * SC_TILE) + q;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long e = e0; e < e1; ++e) {
+            const float ww = w32[e];
+            const float4 z = Y[(int64_t)indices_r[e] * 4];
+            s.x = __fadd_rn(s.x, __fmul_rn(ww, z.x)); s.y = __fadd_rn(s.y, __fmul_rn(ww, z.y));
+            s.z = __fadd_rn(s.z, __fmul_rn(ww, z.z)); s.w = __fadd_rn(s.w, __fmul_rn(ww, z.w));
+        }
+        const float4 zi = Y[r * 4];
+        cx += fabsf(__fmul_rn(zi.x, s.x)) >= ax; cy += fabsf(__fmul_rn(zi.y, s.y)) >= ay;
+        cz += fabsf(__fmul_rn(zi.z, s.z)) >= az; cw += fabsf(__fmul_rn(zi.w, s.w)) >= aw;
+    }
+    int4 *dst = reinterpret_cast<int4 *>(count) + o;
+    if (first) *dst = make_int4(cx, cy, cz, cw);
+    else { const int4 c0 = *dst; *dst = make_int4(c0.x + cx, c0.y + cy, c0.z + cz, c0.w + cw); }
+}
+
 // tile layout [tile][cell][16] -> row-major [cell][n_genes]
 template <typename T>
 __global__ __launch_bounds__(256) void k_untile(const T *__restrict__ tiles, T *__restrict__ out, int64_t n,
@@ -1735,11 +1794,24 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
     dim3 gc((unsigned)ceil_div64(n * 4, 256), (unsigned)T);
     hipLaunchKernelGGL(k_lm_observed, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                        c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, Lag32, I32, n);
-    if (n_perm > 0) {
+    if (n_perm > 0 && c->lm_direct) {   // r01 form (development A/B, sc_ctx_set_local_moran_direct)
         KernelTimerScope ts(c, SC_K_LEE_PERM);
         hipLaunchKernelGGL(k_lm_perm_count, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                            c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, I32,
                            c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, cnt, n);
+    } else if (n_perm > 0) {
+        SC_TRY(sc_graph_ensure_order(c));
+        SC_TRY(c->lm_ys.ensure(sizeof(float) * (size_t)LM_PERM_BATCH * tile_f, &c->mem));
+        KernelTimerScope ts(c, SC_K_LEE_PERM);
+        for (int64_t p0 = 0; p0 < n_perm; p0 += LM_PERM_BATCH) {
+            const int nb = (int)(n_perm - p0 < LM_PERM_BATCH ? n_perm - p0 : LM_PERM_BATCH);
+            hipLaunchKernelGGL(k_lm_gather_sorted, dim3(gc.x, (unsigned)T, (unsigned)nb), dim3(256), 0, c->stream, Z32,
+                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (perm_row0 + p0) * c->p_stride, c->p_stride,
+                               n, T, c->lm_ys.as<float>());
+            hipLaunchKernelGGL(k_lm_count_sorted, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                               c->g_indices_r.as<int32_t>(), c->g_w32.as<float>(), c->g_order.as<int32_t>(),
+                               c->lm_ys.as<float>(), I32, nb, T, cnt, n, p0 == 0 ? 1 : 0);
+        }
     }
     SC_HIP(hipGetLastError());
     // un-tile into row-major (cells x genes) staging and copy back
