@@ -114,37 +114,6 @@ def _radius_weights(ctx, coords: np.ndarray, radius: float, float32_weights: boo
 # =============================================================================================
 
 
-def _fdr_correction_bh(p_values: np.ndarray) -> np.ndarray:
-    """Benjamini-Hochberg adjusted p-values (AC:132-164)."""
-    n = len(p_values)
-    if n == 0:
-        return p_values.copy()
-    order = np.argsort(p_values)
-    adj = p_values[order] * n / np.arange(1, n + 1)
-    adj = np.minimum.accumulate(adj[::-1])[::-1]
-    out = np.empty(n)
-    out[order] = adj
-    return np.clip(out, 0, 1)
-
-
-def _fdr_correction_bonferroni(p_values: np.ndarray) -> np.ndarray:
-    """Bonferroni adjusted p-values (AC:167-183)."""
-    n = len(p_values)
-    if n == 0:
-        return p_values.copy()
-    return np.clip(p_values * n, 0, 1)
-
-
-def _apply_fdr_correction(p_values: np.ndarray, method: str) -> np.ndarray:
-    if method == "none":
-        return p_values.copy()
-    if method == "bonferroni":
-        return _fdr_correction_bonferroni(p_values)
-    if method == "fdr_bh":
-        return _fdr_correction_bh(p_values)
-    raise ValueError(f"Unknown FDR method: {method}")
-
-
 def _classify_quadrants(z_values, lag_values, p_values=None, alpha: float = 0.05) -> np.ndarray:
     """LISA quadrants as int8 (AC:219-265): 1=HH, 2=LL, 3=HL, 4=LH, 0=NS / not significant."""
     q = np.zeros(np.shape(z_values), dtype=np.int8)
@@ -447,30 +416,13 @@ def lees_l(
 # =============================================================================================
 
 
-def _bh_from_counts(counts: np.ndarray, n_permutations: int) -> np.ndarray:
-    """Benjamini-Hochberg adjusted p-values of one gene from its per-cell permutation counts.
-
-    Same numbers as ``_fdr_correction_bh`` on ``p = float32((count + 1) / (P + 1))`` (AC:132-164,
-    894-896) without sorting N values: p takes at most P + 1 levels, and after the reference's
-    cumulative minimum every cell of a level gets ``min over higher-or-equal levels of p * n / (last
-    rank of that level)`` -- evaluated here with the reference's own dtypes (float32 product,
-    float64 quotient, float32 store)."""
-    n = counts.size
-    hist = np.bincount(counts, minlength=n_permutations + 1)[: n_permutations + 1]
-    levels = ((np.arange(n_permutations + 1) + 1) / (n_permutations + 1)).astype(np.float32)
-    last_rank = np.cumsum(hist)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        a = (levels * np.float32(n)).astype(np.float64) / last_rank
-    a[hist == 0] = np.inf
-    a = np.minimum.accumulate(a[::-1])[::-1]
-    return np.clip(a, 0, 1).astype(np.float32)[counts]
-
-
 def _padj_tables(hist: np.ndarray, n_cells: int, n_permutations: int, method: str) -> np.ndarray:
     """Adjusted p-value of every permutation-count level, per gene: ``tab[g, c]`` is what the reference's FDR step
     (AC:132-183 applied per gene at AC:912-920) gives a cell of gene g whose count is c.  ``hist[g, c]`` = number of
-    cells at that level.  Same dtypes as the reference: float32 levels, float32 product, float64 quotient, float32
-    store (see ``_bh_from_counts``, which this vectorises over genes)."""
+    cells at that level.  Benjamini-Hochberg without sorting N values: p takes at most P + 1 levels, and after the
+    reference's cumulative minimum every cell of a level gets ``min over higher-or-equal levels of p * n / (last rank of
+    that level)`` -- evaluated with the reference's own dtypes (float32 levels, float32 product, float64 quotient,
+    float32 store); ``tests/test_cpu_properties.py`` proves it equal, bit for bit, to the sort-based form."""
     levels = ((np.arange(n_permutations + 1) + 1) / (n_permutations + 1)).astype(np.float32)
     if method == "none":
         return np.tile(levels, (hist.shape[0], 1))

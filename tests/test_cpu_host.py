@@ -88,17 +88,13 @@ def test_host_permutation_generator_matches_numpy():
         _lib.rng_state_words(np.random.Generator(np.random.MT19937(1)))
 
 
-def test_fdr_and_quadrants_match_reference_golden():
+def test_quadrants_match_reference_golden(oracle):
     from spatialcore_amd.spatial import autocorrelation as ac
 
     g = load_golden("ref_fdr_quadrants.npz")
-    np.testing.assert_array_equal(ac._fdr_correction_bh(g["p"]), g["bh"])
-    np.testing.assert_array_equal(ac._fdr_correction_bonferroni(g["p"]), g["bonf"])
-    np.testing.assert_array_equal(ac._apply_fdr_correction(g["p"], "none"), g["p"])
     np.testing.assert_array_equal(ac._classify_quadrants(g["z"], g["lag"], g["pq"], 0.05), g["quad_sig"])
     np.testing.assert_array_equal(ac._classify_quadrants(g["z"], g["lag"]), g["quad_nosig"])
-    with pytest.raises(ValueError):
-        ac._apply_fdr_correction(g["p"], "holm")
+    np.testing.assert_array_equal(oracle.quadrants(g["z"], g["lag"], g["pq"], 0.05), g["quad_sig"])
 
 
 def test_simple_anndata_and_metadata():

@@ -8,11 +8,12 @@ from conftest import load_golden
 
 @settings(max_examples=200, deadline=None)
 @given(st.integers(1, 60), st.integers(1, 400), st.integers(0, 2**32 - 1))
-def test_bh_from_counts_equals_reference_bh(n_perm, n_cells, seed):
-    """The O(P) count-level Benjamini-Hochberg used by local_morans_i gives, bit for bit, what the
-    reference's sort-based _fdr_correction_bh (AC:132-164) gives on p = float32((c + 1) / (P + 1)),
-    stored into a float32 column as the reference does (AC:912-914)."""
-    from spatialcore_amd.spatial.autocorrelation import _bh_from_counts, _fdr_correction_bh
+def test_count_level_bh_equals_sort_based_bh(n_perm, n_cells, seed):
+    """The O(P) count-level Benjamini-Hochberg tables used by local_morans_i give, bit for bit, what the
+    reference's sort-based BH (AC:132-164; restated in the oracle, pinned by the reference's golden below) gives on
+    p = float32((c + 1) / (P + 1)), stored into a float32 column as the reference does (AC:912-914)."""
+    import oracle as orc
+    from spatialcore_amd.spatial.autocorrelation import _padj_tables
 
     rng = np.random.default_rng(seed)
     counts = rng.integers(0, n_perm + 1, n_cells).astype(np.int32)
@@ -20,17 +21,19 @@ def test_bh_from_counts_equals_reference_bh(n_perm, n_cells, seed):
         counts[:] = rng.integers(0, n_perm + 1)          # all tied
     p32 = ((counts + 1) / (n_perm + 1)).astype(np.float32)
     want = np.ones(n_cells, dtype=np.float32)
-    want[:] = _fdr_correction_bh(p32)                   # float64 result assigned into a float32 column
-    got = _bh_from_counts(counts, n_perm)
+    want[:] = orc.fdr_bh(p32)                           # float64 result assigned into a float32 column
+    hist = np.bincount(counts, minlength=n_perm + 1)[None, :]
+    got = _padj_tables(hist, n_cells, n_perm, "fdr_bh")[0][counts]
     assert got.dtype == np.float32
     np.testing.assert_array_equal(got, want)
 
 
-def test_bh_matches_reference_golden_values():
-    from spatialcore_amd.spatial.autocorrelation import _fdr_correction_bh
+def test_oracle_bh_matches_reference_golden_values():
+    import oracle as orc
 
     g = load_golden("ref_fdr_quadrants.npz")
-    np.testing.assert_array_equal(_fdr_correction_bh(g["p"]), g["bh"])
+    np.testing.assert_array_equal(orc.fdr_bh(g["p"]), g["bh"])
+    np.testing.assert_array_equal(orc.bonferroni(g["p"]), g["bonf"])
 
 
 @settings(max_examples=200, deadline=None)
@@ -86,8 +89,9 @@ def test_quadrant_rules():
 
 def test_padj_tables_match_per_gene_corrections():
     """The per-(gene, count level) lookup tables handed to the device finalisation of local_morans_i give exactly
-    what the reference's per-gene FDR functions give cell by cell (BH via the count-level form, Bonferroni, none)."""
-    from spatialcore_amd.spatial.autocorrelation import (_apply_fdr_correction, _bh_from_counts, _padj_tables)
+    what the reference's per-gene FDR functions give cell by cell (BH, Bonferroni, none; oracle restatements)."""
+    import oracle as orc
+    from spatialcore_amd.spatial.autocorrelation import _padj_tables
 
     rng = np.random.default_rng(5)
     n, P, G = 5000, 19, 6
@@ -96,9 +100,11 @@ def test_padj_tables_match_per_gene_corrections():
     counts[:, 3] = rng.integers(0, 3, n)   # only a few levels populated
     hist = np.stack([np.bincount(counts[:, g], minlength=P + 1) for g in range(G)])
     p = ((counts + 1) / (P + 1)).astype(np.float32)
-    for method in ("fdr_bh", "bonferroni", "none"):
+    correct = {"fdr_bh": orc.fdr_bh, "bonferroni": orc.bonferroni, "none": lambda v: v.copy()}
+    for method, fn in correct.items():
         tab = _padj_tables(hist, n, P, method)
         assert tab.dtype == np.float32 and tab.shape == (G, P + 1)
         for g in range(G):
-            want = _bh_from_counts(counts[:, g], P) if method == "fdr_bh" else _apply_fdr_correction(p[:, g], method)
+            want = np.ones(n, dtype=np.float32)
+            want[:] = fn(p[:, g])
             np.testing.assert_array_equal(tab[g][counts[:, g]], want, err_msg=f"{method} gene {g}")
