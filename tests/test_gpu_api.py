@@ -116,6 +116,44 @@ def test_lees_l_constant_gene_at_awkward_cell_count(oracle):
     assert np.isnan(ad.uns["morans_i"]["I"].values[1])
 
 
+def test_radius_keyword_extension_for_moran_and_lee(oracle):
+    """`radius=` (extension for BASELINE configs[2]; the reference's Moran / Lee functions only take n_neighbors):
+    closed-ball radius graph, self excluded, row-normalised -- against the oracle on the same graph."""
+    from scipy.sparse import csr_matrix
+    from spatialcore_amd.spatial import lees_l, morans_i
+
+    n, G, P, r = 3000, 6, 29, 10.0
+    coords, X = synth(n, G, 12, dtype=np.float64, sparse_x=False)
+    indptr, indices = oracle.radius_neighbors(coords, r)
+    assert (np.diff(indptr) > 0).mean() > 0.9 and (np.diff(indptr) == 0).any()     # some isolated cells: empty rows stay
+    conn = csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    ad = make_adata(coords, X)
+    morans_i(ad, genes=[f"g{i}" for i in range(G)], n_permutations=P, seed=2, radius=r)
+    tab = oracle.morans_i_reference_table(coords, X, list(range(G)), 6, P, seed=2, graph=conn)
+    np.testing.assert_allclose(ad.uns["morans_i"]["I"].values, tab["I"], rtol=1e-9)
+    np.testing.assert_allclose(ad.uns["morans_i"]["z_score"].values, tab["z_score"], rtol=1e-9)
+    ties = (np.abs(tab["sims"] - tab["I"]) <= 1e-11 * np.abs(tab["I"])).sum(axis=0)
+    assert (np.abs(ad.uns["morans_i"]["p_value"].values - tab["p_value"]) <= ties / (P + 1) + 1e-15).all()
+    assert ad.obsp["spatial_connectivities"].nnz == indices.size
+    assert ad.uns["spatial_neighbors"]["params"]["radius"] == r
+    # Lee: float32 row-normalised weights like build_spatial_weights, the reference's core loop on that W
+    deg = np.diff(indptr)
+    w = np.repeat(np.where(deg > 0, np.float32(1.0) / np.maximum(deg, 1).astype(np.float32), 0).astype(np.float32), deg)
+    W = csr_matrix((w, indices, indptr), shape=(n, n))
+    rng = np.random.default_rng(5)
+    want = []
+    for a, b in [(0, 1), (2, 3)]:
+        zx = (X[:, a] - X[:, a].mean()) / X[:, a].std()
+        zy = (X[:, b] - X[:, b].mean()) / X[:, b].std()
+        _, L, _, p, _ = oracle.lees_l_core(zx, zy, W.astype(np.float64), 19, rng)
+        want.append((L, p))
+    got = lees_l(ad, [("g0", "g1"), ("g2", "g3")], n_permutations=19, seed=5, radius=r)
+    for gq, (L, p) in zip(got, want):
+        assert gq["L"] == pytest.approx(L, rel=1e-9) and gq["p_value"] == p
+    with pytest.raises(ValueError, match="radius must be > 0"):
+        morans_i(ad, n_permutations=2, radius=0.0)
+
+
 def test_neighborhood_profile_golden():
     from spatialcore_amd.spatial import compute_neighborhood_profile
 
