@@ -6,7 +6,12 @@ reference src/spatialcore/spatial/autocorrelation.py, abbreviated ``AC`` below).
 the path runs in hand-written HIP kernels behind the C ABI of ``include/spatialcore_hip.h``; there is
 no CPU fallback -- without the shared library or a gfx950 device the functions raise.
 
-Extra keyword (keyword-only, default preserves reference behaviour): ``device`` = GPU ordinal.
+Extra keywords (keyword-only, defaults preserve reference behaviour): ``device`` = GPU ordinal; ``radius`` on
+``morans_i`` / ``lees_l`` (closed-ball radius graph instead of kNN).
+
+Limits of the device path that the reference does not have: 2-D coordinates only; ``n_neighbors <= 64`` (63 with
+``include_self``): the neighbour search keeps a cell's k best candidates in registers (``ValueError`` beyond that);
+``n_cells < 2**25`` for the narrow-source permutation kernels (use ``sc_ctx_set_moran_source_bits(ctx, 64)`` above).
 """
 
 from __future__ import annotations

@@ -260,3 +260,19 @@ def test_config4_shape_5m_cells_indexing():
         np.testing.assert_array_equal(again["sims"], out["sims"])
         np.testing.assert_array_equal(again["I"], out["I"])
         assert np.abs(out["I"]).max() < 0.01                      # i.i.d. genes
+        del host
+        # the bench's chunk schedule (P > 384) at 5M cells: the pipeline against the host generator's state after
+        # 400 x 5M Fisher-Yates steps and against the two-step path on the device-resident table (bit-equal)
+        P2 = 400
+        w = _lib.rng_state_words(np.random.default_rng(3))
+        one = ctx.moran_seeded(w, P2)
+        assert ctx.permgen_stats()[2] == 0 and ctx.moran_source_bits() == 16
+        wh = _lib.rng_state_words(np.random.default_rng(3))
+        last = _lib.perm_numpy_host(wh, n, P2)[P2 - 1].copy()
+        np.testing.assert_array_equal(w, wh)
+        two = ctx.moran(P2)                                       # the table the pipeline left (inverse rows), re-scored
+        for key in ("sims", "count_ge", "sim_sum"):
+            np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+        ctx.set_permutations(last[None, :])                       # the last row, scored from the host's table
+        np.testing.assert_array_equal(ctx.moran(1)["sims"][0], one["sims"][P2 - 1])
+        assert ctx.device_mem() < 120 * 2**30
