@@ -200,6 +200,16 @@ def _norm_sf_cdf(z: np.ndarray) -> np.ndarray:
     return p
 
 
+def _moran_gene_batch(n_cells: int, requested: Optional[int]) -> int:
+    """Genes per device batch of ``morans_i``: X, Z, Lag tiles + the narrow copy = ~28 bytes per (cell, gene)."""
+    if requested is not None:
+        if requested < 1:
+            raise ValueError(f"gene_batch must be >= 1, got {requested}")
+        return int(requested)
+    fit = int((128 << 30) // (28 * max(n_cells, 1)))
+    return max(64, fit // 64 * 64)
+
+
 def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_table: bool = False) -> dict:
     """Global Moran's I on operands already resident on the device (graph + expression tiles):
     numpy-exact permutation table -> lag / permutation kernels -> p-value assembly as squidpy's
@@ -250,6 +260,7 @@ def morans_i(
     *,
     device: int = 0,
     radius: Optional[float] = None,
+    gene_batch: Optional[int] = None,
 ):
     """Global Moran's I with permutation p-values (AC:421-648).
 
@@ -263,8 +274,9 @@ def morans_i(
     ``default_rng(seed).permutation(n)`` stream, each scored as
     ``sum_i z_i * lag[perm[i]]`` (identical to scoring the row-permuted graph).
 
-    Extension (keyword-only, default keeps the reference's behaviour): ``radius`` -- use the closed-ball radius graph
-    (row-normalised) instead of the kNN graph; ``n_neighbors`` is then ignored.
+    Extensions (keyword-only, defaults keep the reference's behaviour): ``radius`` -- use the closed-ball radius graph
+    (row-normalised) instead of the kNN graph, ``n_neighbors`` is then ignored; ``gene_batch`` -- genes resident on
+    the device at a time (default: as many as fit ~128 GB of tiles; results do not depend on it).
     """
     start_time = time.time()
     coords = _require_spatial(adata, spatial_key)
@@ -301,9 +313,23 @@ def morans_i(
         _squidpy_neighbors(ctx, adata, coords, n_neighbors, spatial_key)
 
     cols, where = _unique_columns(adata, gene_names)
-    ctx.set_expression(_expression(adata, layer), cols)
-    res = _moran_resident(ctx, n_cells, n_permutations, seed)
-    score, p_all, var_norm, expected_I = res["I"], res["p_value"], res["var_norm"], res["expected_I"]
+    # Genes are scored in batches that fit the device (four tile sets of n_cells x 8 bytes per gene, ~1/2 of the HBM
+    # left to them); every batch after the first re-uses the permutation table the first one left on the device --
+    # squidpy's permutations are shared by all genes too, so the result does not depend on the batching.
+    X = _expression(adata, layer)
+    per_batch = _moran_gene_batch(n_cells, gene_batch)
+    score, p_all = np.empty(cols.size), np.empty(cols.size)
+    if sparse.issparse(X) and cols.size > per_batch:
+        X = X.tocsc()
+    for b0 in range(0, cols.size, per_batch):
+        part = cols[b0:b0 + per_batch]
+        if sparse.issparse(X) and cols.size > per_batch:
+            ctx.set_expression(X[:, part], np.arange(part.size, dtype=np.int32))
+        else:
+            ctx.set_expression(X, part)
+        res = _moran_resident(ctx, n_cells, n_permutations, seed, reuse_table=b0 > 0)
+        score[b0:b0 + per_batch], p_all[b0:b0 + per_batch] = res["I"], res["p_value"]
+    var_norm, expected_I = res["var_norm"], res["expected_I"]
 
     results = []
     for gene_name, u in zip(gene_names, where):

@@ -55,6 +55,24 @@ def test_morans_i_table_matches_oracle(oracle):
     np.testing.assert_allclose(ad.uns["m0"]["p_value"].values, t0["p_value"], rtol=1e-6, atol=1e-300)
 
 
+def test_morans_i_gene_batches_share_the_permutation_table():
+    """Genes scored in device batches (a matrix too wide for HBM) see the same permutations: the table of the first
+    batch stays resident.  Batched == unbatched, bit for bit, dense and sparse, 130 permutations (two chunks)."""
+    from spatialcore_amd.spatial import morans_i
+
+    coords, X = synth(70001, 23, 6, dtype=np.float32)
+    genes = [f"g{i}" for i in np.random.default_rng(2).permutation(23)]
+    whole = make_adata(coords, X)
+    morans_i(whole, genes=genes, n_neighbors=6, n_permutations=130, seed=9)
+    for M in (X, X.toarray()):
+        part = make_adata(coords, M)
+        morans_i(part, genes=genes, n_neighbors=6, n_permutations=130, seed=9, gene_batch=7)
+        for col in ("I", "expected_I", "z_score", "p_value"):
+            np.testing.assert_array_equal(part.uns["morans_i"][col].values, whole.uns["morans_i"][col].values, err_msg=col)
+    with pytest.raises(ValueError, match="gene_batch must be >= 1"):
+        morans_i(whole, genes=genes, n_permutations=2, gene_batch=0)
+
+
 def test_morans_i_errors_and_copy():
     from spatialcore_amd.spatial import morans_i
 
