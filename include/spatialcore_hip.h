@@ -184,6 +184,12 @@ int sc_lee_seeded(sc_ctx *ctx, uint64_t *state6, const int32_t *pair_x, const in
  * L32_out[q] is 0 for a pair with a zero-std gene; mean32_out / sd32_out (optional) are [n_pairs][2] (x, y). */
 int sc_lee_observed_f32(sc_ctx *ctx, const int32_t *pair_x, const int32_t *pair_y, int64_t n_pairs, float *L32_out,
                         float *mean32_out, float *sd32_out);
+/* sc_lee_shared (EXTENSION, no reference site: the reference draws fresh permutations per pair, AC:1109-1148): the
+ * full grid genes_x x genes_y under ONE shared block of n_perm numpy-exact permutations.  The permutation statistics
+ * of the grid are then n_perm dense contractions over the cells with a row-gathered operand -- fp64 matrix cores.
+ * L_out / count_abs_ge_out are [n_x][n_y]; L_perm_out (optional) is [n_perm][n_x][n_y].  state6 is advanced. */
+int sc_lee_shared(sc_ctx *ctx, uint64_t *state6, const int32_t *genes_x, int32_t n_x, const int32_t *genes_y,
+                  int32_t n_y, int64_t n_perm, double *L_out, int64_t *count_abs_ge_out, double *L_perm_out);
 
 /* ---- N1: Local Moran's I ---------------------------------------------------------------------
  * Replaces the batch body of local_morans_i (AC:845-896) for the loaded genes (= one batch), with the

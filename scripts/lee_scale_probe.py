@@ -11,6 +11,7 @@ import logging
 logging.getLogger("spatialcore_amd").setLevel(logging.WARNING)
 GX, GY = int(sys.argv[1]), int(sys.argv[2])
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 199
+SHARED = len(sys.argv) > 4 and sys.argv[4] == "shared"   # extension: one block of permutations for all pairs
 N = 1_000_000
 rng = np.random.default_rng(42)
 coords = rng.uniform(0, np.sqrt(N) * 10, (N, 2))
@@ -22,17 +23,18 @@ ad = SimpleAnnData(X, obs=pd.DataFrame(index=pd.RangeIndex(N).astype(str)), var_
                    obsm={"spatial": coords})
 pairs = [(f"g{a}", f"g{GX + b}") for a in range(GX) for b in range(GY)]
 ctx = _lib.default_context(0)
-lees_l(ad, pairs[:2], n_permutations=3, radius=30.0)          # warm-up: allocations
+lees_l(ad, pairs[:2], n_permutations=3, radius=30.0, shared_permutations=SHARED)          # warm-up: allocations
 ctx.reset_timers()
 t0 = time.perf_counter()
-res = lees_l(ad, pairs, n_permutations=P, seed=0, radius=30.0)
+res = lees_l(ad, pairs, n_permutations=P, seed=0, radius=30.0, shared_permutations=SHARED)
 wall = time.perf_counter() - t0
 lee_ms, lee_launches = ctx.kernel_time(_lib.K_LEE_PERM)
 scan_ms, _ = ctx.kernel_time(_lib.K_PERM_SCAN)
 L = np.array([r["L"] for r in res]); p = np.array([r["p_value"] for r in res])
 n_graph, nnz = ctx.graph_shape()
-print(json.dumps({"workload": f"{N} cells, radius 30 um graph ({nnz / N:.1f} neighbours per cell), {GX} x {GY} = {len(pairs)} pairs, "
-                              f"{P} numpy-exact permutations per pair ({len(pairs) * P} permutations of {N} in total)",
+print(json.dumps({"workload": f"{N} cells, radius 30 um graph ({nnz / N:.1f} neighbours per cell), {GX} x {GY} = {len(pairs)} pairs, " +
+                              (f"{P} numpy-exact permutations SHARED by all pairs (extension)" if SHARED else
+                               f"{P} numpy-exact permutations per pair ({len(pairs) * P} permutations of {N} in total)"),
                   "wall_s": wall, "pairs_per_s": len(pairs) / wall, "ms_per_pair": wall / len(pairs) * 1e3,
                   "generator_chain_ms": scan_ms, "lee_row_kernel_ms": lee_ms, "lee_row_kernel_launches": lee_launches,
                   "extrapolated_100x100_s": wall / len(pairs) * 1e4,

@@ -56,6 +56,7 @@ SYMBOLS = {
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_lee_seeded": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
+    "sc_lee_shared": [_P, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P, _P],
     "sc_lee_observed_f32": [_P, _P, _P, c_int64, _P, _P, _P],
     "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
     "sc_local_moran_hist": [_P, _P],
@@ -381,6 +382,15 @@ class Context:
         cnt = np.zeros(q, dtype=np.int64)
         Lp = np.empty((q, n_perm), dtype=np.float64) if return_perms else None
         _check(self._lib.sc_lee_seeded(self._h, _ptr(words), _ptr(px), _ptr(py), q, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
+        return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
+
+    def lee_shared(self, words, genes_x, genes_y, n_perm: int, return_perms: bool = False):
+        """EXTENSION: the full grid genes_x x genes_y under one shared block of permutations (fp64 MFMA contractions)."""
+        gx, gy = _c(genes_x, np.int32), _c(genes_y, np.int32)
+        L = np.empty((gx.size, gy.size), dtype=np.float64)
+        cnt = np.zeros((gx.size, gy.size), dtype=np.int64)
+        Lp = np.empty((n_perm, gx.size, gy.size), dtype=np.float64) if return_perms else None
+        _check(self._lib.sc_lee_shared(self._h, _ptr(words), _ptr(gx), gx.size, _ptr(gy), gy.size, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
         return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
 
     def lee_observed_f32(self, pair_x, pair_y) -> np.ndarray:

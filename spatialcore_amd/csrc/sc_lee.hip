@@ -493,3 +493,207 @@ extern "C" int sc_lee_observed_f32(sc_ctx *c, const int32_t *pair_x, const int32
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// EXTENSION: all pairs of an x-gene list and a y-gene list under SHARED permutations.
+//
+// The reference draws a fresh block of permutations for every pair, which makes a 100 x 100 screen cost 2 x 10^6
+// permutations of the cells (sc_lee_seeded: 36 ms per pair, generator-bound).  When ONE block of P permutations is
+// shared by all pairs (each pair's null is still "y shuffled against x"; the nulls of different pairs are correlated),
+// the permutation statistics of the whole grid are P dense contractions over the cells,
+//     L_p[x][y] = sum_j U[j][x] * Zy[perm_p[j]][y],
+// i.e. the permutation x gene batch becomes a true GEMM with a row-gathered B operand: fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64), A = 16 x-genes of 4 cells (coalesced 512 bytes), B = 16 y-genes of the 4 permuted cells
+// (four gathered 128-byte rows).  A wavefront keeps the accumulators of up to 8 x-tiles, so every gathered row is
+// used for 128 x-genes.
+// ------------------------------------------------------------------------------------------------
+
+// out tiles [t][cell][16] = column genes[16 t + s] of the source tiles (0 beyond n_genes)
+__global__ __launch_bounds__(256) void k_repack_tiles(const double *__restrict__ T, int64_t n, const int32_t *__restrict__ genes,
+                                                      int n_genes, double *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cell = t >> 4;
+    const int s = (int)(t & 15);
+    if (cell >= n) return;
+    const int k = blockIdx.y * 16 + s;
+    double v = 0.0;
+    if (k < n_genes) { const int32_t g = genes[k]; v = T[(int64_t)(g >> 4) * n * SC_TILE + cell * SC_TILE + (g & 15)]; }
+    out[(int64_t)blockIdx.y * n * SC_TILE + cell * SC_TILE + s] = v;
+}
+
+#define LEE_SH_CELLS 16384   // cells per workgroup (4 wavefronts x 4096)
+#define LEE_SH_XT 8          // x tiles per wavefront pass
+
+// partial[p][yt][xt][block][256]: sums over the block's cells of U_xt[cell][x] * Zy_yt[perm_p[cell]][y]
+__global__ __launch_bounds__(256) void k_lee_shared_mfma(const double *__restrict__ Ux, const double *__restrict__ Zy,
+                                                         int64_t n, const int32_t *__restrict__ perm, int64_t pstride,
+                                                         int xt0, int xt_n, int x_tiles, int y_tiles,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double red[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int yt = blockIdx.y, p = blockIdx.z;
+    const double *B = Zy + (int64_t)yt * n * SC_TILE;
+    const int32_t *prow = perm + (int64_t)p * pstride;
+    const int64_t c0 = (int64_t)blockIdx.x * LEE_SH_CELLS + (int64_t)wave * (LEE_SH_CELLS / 4);
+    int64_t c1 = c0 + LEE_SH_CELLS / 4;
+    if (c1 > n) c1 = n;
+    v4f64 acc[LEE_SH_XT];
+#pragma unroll
+    for (int k = 0; k < LEE_SH_XT; ++k) acc[k] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = c0; c < c1; c += 4) {
+        const int64_t cell = c + (lane >> 4);
+        const bool live = cell < c1;
+        const double b = live ? B[(int64_t)prow[cell] * SC_TILE + (lane & 15)] : 0.0;
+#pragma unroll
+        for (int k = 0; k < LEE_SH_XT; ++k) {
+            if (k < xt_n) {
+                const double a = live ? Ux[(int64_t)(xt0 + k) * n * SC_TILE + cell * SC_TILE + (lane & 15)] : 0.0;
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LEE_SH_XT; ++k) {   // (unrolled: a runtime index into acc[] would put it in scratch)
+        if (k < xt_n) {                       // uniform for the whole workgroup
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[wave][((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[k][v];
+            __syncthreads();
+            const int t = threadIdx.x;
+            partial[((((int64_t)p * y_tiles + yt) * x_tiles + xt0 + k) * gridDim.x + blockIdx.x) * 256 + t] =
+                (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        }
+    }
+}
+
+// L_p[x][y] = sum over blocks (ascending); count[x][y] += |L_p| >= |obs[x][y]|; optional copy of L_p
+__global__ __launch_bounds__(256) void k_lee_shared_count(const double *__restrict__ partial, int blocks, int x_tiles, int y_tiles,
+                                                          int n_x, int n_y, int n_perm_chunk, const double *__restrict__ obs,
+                                                          unsigned long long *__restrict__ count, double *__restrict__ lperm_out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)n_x * n_y;
+    if (t >= per * n_perm_chunk) return;
+    const int p = (int)(t / per);
+    const int x = (int)((t % per) / n_y), y = (int)(t % n_y);
+    const double *src = partial + ((((int64_t)p * y_tiles + (y >> 4)) * x_tiles + (x >> 4)) * blocks) * 256 + (x & 15) * 16 + (y & 15);
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += src[(int64_t)b * 256];
+    if (fabs(s) >= fabs(obs[(int64_t)x * n_y + y])) atomicAdd(&count[(int64_t)x * n_y + y], 1ull);
+    if (lperm_out) lperm_out[t] = s;
+}
+
+extern "C" int sc_lee_shared(sc_ctx *c, uint64_t *state6, const int32_t *genes_x, int32_t n_x, const int32_t *genes_y,
+                             int32_t n_y, int64_t n_perm, double *L_out, int64_t *count_abs_ge_out, double *L_perm_out)
+{
+    SC_REQUIRE(c && genes_x && genes_y && L_out && count_abs_ge_out, SC_ERR_INVALID, "sc_lee_shared: null pointer");
+    SC_REQUIRE(n_x >= 1 && n_y >= 1 && n_perm >= 0, SC_ERR_INVALID, "sc_lee_shared: bad sizes");
+    SC_REQUIRE(n_perm == 0 || state6, SC_ERR_INVALID, "sc_lee_shared: generator state required when n_perm > 0");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0 && c->g_n == c->e_n, SC_ERR_STATE, "sc_lee_shared: expression / graph missing");
+    const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
+    for (int k = 0; k < n_x; ++k) SC_REQUIRE(genes_x[k] >= 0 && genes_x[k] < G, SC_ERR_INVALID, "sc_lee_shared: x gene out of range");
+    for (int k = 0; k < n_y; ++k) SC_REQUIRE(genes_y[k] >= 0 && genes_y[k] < G, SC_ERR_INVALID, "sc_lee_shared: y gene out of range");
+    const size_t tile_bytes = (size_t)n * SC_TILE * sizeof(double);
+    const int XT = (n_x + 15) / 16, YT = (n_y + 15) / 16;
+    const int64_t per = (int64_t)n_x * n_y;
+    // z-scores (zero-variance genes -> 0: their L and every L_perm are 0, count = n_perm, p = 1), lag, U
+    SC_TRY(sc_expr_zscores(c));
+    SC_TRY(c->Lag.ensure((size_t)T * tile_bytes, &c->mem));
+    SC_TRY(sc_lag_tiles(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>()));
+    SC_TRY(sc_graph_ensure_transpose(c));
+    SC_TRY(c->lee_U.ensure((size_t)T * tile_bytes, &c->mem));
+    SC_TRY(sc_lag_tiles(c, c->gt_indptr, c->gt_indices, c->gt_data, c->Z.as<double>(), c->lee_U.as<double>()));
+    // compact tile sets: Zx (observed), Ux (permutations) over the x genes; LagY (observed), Zy (permutations) over the y genes
+    SC_TRY(c->lee_Uc.ensure((size_t)(2 * XT) * tile_bytes, &c->mem));
+    SC_TRY(c->lee_Zc.ensure((size_t)(2 * YT) * tile_bytes, &c->mem));
+    SC_TRY(c->lee_a.ensure(sizeof(int32_t) * (size_t)(n_x + n_y), &c->mem));
+    int32_t *d_gx = c->lee_a.as<int32_t>(), *d_gy = d_gx + n_x;
+    SC_HIP(hipMemcpyAsync(d_gx, genes_x, sizeof(int32_t) * (size_t)n_x, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemcpyAsync(d_gy, genes_y, sizeof(int32_t) * (size_t)n_y, hipMemcpyHostToDevice, c->stream));
+    double *Zx = c->lee_Uc.as<double>(), *Ux = Zx + (size_t)XT * n * SC_TILE;
+    double *LagY = c->lee_Zc.as<double>(), *Zy = LagY + (size_t)YT * n * SC_TILE;
+    const unsigned gcell = (unsigned)ceil_div64(n * 16, 256);
+    hipLaunchKernelGGL(k_repack_tiles, dim3(gcell, (unsigned)XT), dim3(256), 0, c->stream, c->Z.as<double>(), n, d_gx, (int)n_x, Zx);
+    hipLaunchKernelGGL(k_repack_tiles, dim3(gcell, (unsigned)XT), dim3(256), 0, c->stream, c->lee_U.as<double>(), n, d_gx, (int)n_x, Ux);
+    hipLaunchKernelGGL(k_repack_tiles, dim3(gcell, (unsigned)YT), dim3(256), 0, c->stream, c->Lag.as<double>(), n, d_gy, (int)n_y, LagY);
+    hipLaunchKernelGGL(k_repack_tiles, dim3(gcell, (unsigned)YT), dim3(256), 0, c->stream, c->Z.as<double>(), n, d_gy, (int)n_y, Zy);
+    // observed grid: the identity "permutation" through the same contraction kernel shape (k_lee_observed_mfma)
+    std::vector<int2> tps;
+    for (int a = 0; a < XT; ++a) for (int b = 0; b < YT; ++b) tps.push_back(make_int2(a, b));
+    const int oblocks = (int)ceil_div64(n, LEE_OBS_CELLS);
+    SC_TRY(c->lee_pairs.ensure(sizeof(int2) * tps.size(), &c->mem));
+    SC_HIP(hipMemcpyAsync(c->lee_pairs.p, tps.data(), sizeof(int2) * tps.size(), hipMemcpyHostToDevice, c->stream));
+    const int sblocks = (int)ceil_div64(n, LEE_SH_CELLS);
+    const int64_t chunk_max = n_perm < PERM_CHUNK ? (n_perm > 0 ? n_perm : 1) : PERM_CHUNK;
+    const size_t part_obs = tps.size() * (size_t)oblocks * 256, part_perm = (size_t)chunk_max * YT * XT * sblocks * 256;
+    SC_TRY(c->lee_part.ensure(sizeof(double) * std::max(part_obs, part_perm), &c->mem));
+    SC_TRY(c->lee_obs.ensure(sizeof(double) * (size_t)per, &c->mem));
+    SC_TRY(c->lee_cnt.ensure(sizeof(unsigned long long) * (size_t)per * 2, &c->mem));
+    unsigned long long *d_cnt_backup = c->lee_cnt.as<unsigned long long>() + per;
+    SC_HIP(hipMemsetAsync(c->lee_cnt.p, 0, sizeof(unsigned long long) * (size_t)per, c->stream));
+    hipLaunchKernelGGL(k_lee_observed_mfma, dim3((unsigned)oblocks, (unsigned)tps.size()), dim3(256), 0, c->stream, Zx, LagY, n,
+                       c->lee_pairs.as<int2>(), c->lee_part.as<double>());
+    // pick: obs[x][y] from tile pair (x >> 4) * YT + (y >> 4): reuse k_lee_shared_count's addressing with one "permutation"
+    // whose partial layout is [yt][xt] -- the observed kernel wrote [tile pair = xt * YT + yt]; a tiny dedicated pick instead:
+    {
+        std::vector<int32_t> tp((size_t)per), px((size_t)per), py((size_t)per);
+        for (int x = 0; x < n_x; ++x)
+            for (int y = 0; y < n_y; ++y) {
+                tp[(size_t)x * n_y + y] = (x >> 4) * YT + (y >> 4);
+                px[(size_t)x * n_y + y] = x;
+                py[(size_t)x * n_y + y] = y;
+            }
+        SC_TRY(c->lee_rowmap.ensure(sizeof(int32_t) * 3 * (size_t)per, &c->mem));
+        int32_t *d_tp = c->lee_rowmap.as<int32_t>();
+        SC_HIP(hipMemcpyAsync(d_tp, tp.data(), sizeof(int32_t) * (size_t)per, hipMemcpyHostToDevice, c->stream));
+        SC_HIP(hipMemcpyAsync(d_tp + per, px.data(), sizeof(int32_t) * (size_t)per, hipMemcpyHostToDevice, c->stream));
+        SC_HIP(hipMemcpyAsync(d_tp + 2 * per, py.data(), sizeof(int32_t) * (size_t)per, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_lee_observed_pick, dim3((unsigned)ceil_div64(per, 256)), dim3(256), 0, c->stream,
+                           c->lee_part.as<double>(), oblocks, d_tp, d_tp + per, d_tp + 2 * per, per, c->lee_obs.as<double>());
+        SC_HIP(hipGetLastError());
+        SC_HIP(hipStreamSynchronize(c->stream));   // host vectors
+    }
+    if (n_perm > 0) {
+        if (L_perm_out) SC_TRY(c->lee_lperm.ensure(sizeof(double) * (size_t)per * (size_t)n_perm, &c->mem));
+        auto score = [&](int64_t p0, int64_t p1) -> int {
+            const int cnt = (int)(p1 - p0);
+            for (int xt0 = 0; xt0 < XT; xt0 += LEE_SH_XT) {
+                const int xt_n = XT - xt0 < LEE_SH_XT ? XT - xt0 : LEE_SH_XT;
+                KernelTimerScope ts(c, SC_K_LEE_PERM);
+                hipLaunchKernelGGL(k_lee_shared_mfma, dim3((unsigned)sblocks, (unsigned)YT, (unsigned)cnt), dim3(256), 0, c->stream,
+                                   Ux, Zy, n, c->perm.as<int32_t>() + p0 * c->p_stride, c->p_stride, xt0, xt_n, XT, YT,
+                                   c->lee_part.as<double>());
+            }
+            hipLaunchKernelGGL(k_lee_shared_count, dim3((unsigned)ceil_div64(per * cnt, 256)), dim3(256), 0, c->stream,
+                               c->lee_part.as<double>(), sblocks, XT, YT, (int)n_x, (int)n_y, cnt, c->lee_obs.as<double>(),
+                               c->lee_cnt.as<unsigned long long>(),
+                               L_perm_out ? c->lee_lperm.as<double>() + p0 * per : (double *)nullptr);
+            SC_HIP(hipGetLastError());
+            return SC_OK;
+        };
+        SC_HIP(hipMemcpyAsync(d_cnt_backup, c->lee_cnt.p, sizeof(unsigned long long) * (size_t)per, hipMemcpyDeviceToDevice, c->stream));
+        const int ahead = c->pg_ahead;
+        c->pg_ahead = 2;
+        int rc = sc_perm_pipeline(c, state6, n, n_perm, 0, nullptr, score);
+        if (rc == SC_PERMGEN_RETRY) {
+            SC_HIP(hipMemcpyAsync(c->lee_cnt.p, d_cnt_backup, sizeof(unsigned long long) * (size_t)per, hipMemcpyDeviceToDevice, c->stream));
+            const int mode = c->pg_mode;
+            c->pg_mode = 1;
+            rc = sc_perm_pipeline(c, state6, n, n_perm, 0, nullptr, score);
+            c->pg_mode = mode;
+        }
+        c->pg_ahead = ahead;
+        SC_TRY(rc);
+        if (L_perm_out)
+            SC_HIP(hipMemcpyAsync(L_perm_out, c->lee_lperm.p, sizeof(double) * (size_t)per * (size_t)n_perm, hipMemcpyDeviceToHost, c->stream));
+    }
+    std::vector<unsigned long long> cnt((size_t)per);
+    SC_HIP(hipMemcpyAsync(L_out, c->lee_obs.p, sizeof(double) * (size_t)per, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(cnt.data(), c->lee_cnt.p, sizeof(unsigned long long) * (size_t)per, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t q = 0; q < per; ++q) count_abs_ge_out[q] = (int64_t)cnt[(size_t)q];
+    return SC_OK;
+}

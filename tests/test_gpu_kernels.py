@@ -599,6 +599,35 @@ def test_lee_observed_float32_is_numpys_own_number(ctx, oracle, n):
         ctx.lee_observed_f32(pairs[:, 0], pairs[:, 1])
 
 
+def test_lee_shared_permutation_grid_mfma(ctx, oracle):
+    """EXTENSION: the genes_x x genes_y grid under one shared block of permutations (fp64 MFMA with a row-gathered
+    operand) against the reference's core loop restated with that one table: L, every L_perm, the counts."""
+    from spatialcore_amd._lib import rng_state_words
+
+    n, G, P = 9000, 45, 21
+    coords, X = synth(n, G, 33, dtype=np.float64, sparse_x=False)
+    X[:, 3] = 1.0                                                # zero variance on the x side
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(float(np.float32(1.0) / np.float32(6)))
+    ctx.set_expression(X, np.arange(G))
+    gx, gy = np.array([0, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 40]), np.arange(23, 44)
+    w = rng_state_words(np.random.default_rng(8))
+    out = ctx.lee_shared(w, gx, gy, P, return_perms=True)
+    perms, wfin = oracle.perm_table(8, n, P)
+    np.testing.assert_array_equal(w, wfin)
+    W = oracle.reference_weights(coords, 6).astype(np.float64)
+    sd = X.std(axis=0)
+    Z = np.where(sd > 0, (X - X.mean(axis=0)) / np.where(sd > 0, sd, 1), 0.0)
+    U = W.T @ Z[:, gx]
+    L = Z[:, gx].T @ (W @ Z[:, gy])
+    np.testing.assert_allclose(out["L"], L, rtol=1e-10, atol=1e-9)
+    Lp = np.stack([U.T @ Z[perms[p]][:, gy] for p in range(P)])
+    np.testing.assert_allclose(out["L_perm"], Lp, rtol=1e-9, atol=1e-8)
+    want = (np.abs(Lp) >= np.abs(L)[None]).sum(axis=0)
+    np.testing.assert_array_equal(out["count_abs_ge"], want)
+    assert (out["count_abs_ge"][1] == P).all() and (out["L"][1] == 0).all()      # the constant gene: p = 1
+
+
 def test_profile_counts_golden(ctx):
     g = load_golden("ref_profile.npz")
     coords, labels = g["coords"], g["labels"]
