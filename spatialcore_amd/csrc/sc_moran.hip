@@ -632,21 +632,15 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     const int lcell0 = lane / ROW, ltile = (lane % ROW) >> 3;
     double2 *lw = &lds_lag[wave][0][0];
     const int pgroups = (n_perm + 7) >> 3;
-    // XCD-aware task assignment: workgroups are dealt to the 8 XCDs round-robin (XCD = blockIdx % 8), and every XCD has
-    // its own L2.  XCD x takes the cell splits s = x (mod 8) only, so a split's lag rows are fetched from HBM by ONE L2
-    // instead of eight (PMC before: 1.27 x the compulsory bytes, the excess being exactly 7 x the lag rows).
-    // (If the placement were different the result would be the same, only the traffic higher.)
-    const int classes = gridDim.x < 8 ? (int)gridDim.x : 8;                // (a grid of fewer than 8 workgroups: as many classes)
-    const int xcd = (int)(blockIdx.x % classes);
-    const int wgs_here = ((int)gridDim.x - xcd + classes - 1) / classes;    // workgroups of this class
-    const int splits_here = (n_splits - xcd + classes - 1) / classes;       // splits s = xcd, xcd + classes, ... (may be 0)
-    const int64_t n_tasks = (int64_t)n_groups * splits_here * pgroups;
-    const int64_t worker = (int64_t)(blockIdx.x / classes) * SCORE_WAVES + wave, workers = (int64_t)wgs_here * SCORE_WAVES;
+    // (Measured and dropped in r02: giving each XCD -- blockIdx % 8 -- its own subset of the cell splits, so that a
+    //  split's lag rows are fetched by one L2 only: same launch time, same PMC traffic.)
+    const int64_t n_tasks = (int64_t)n_groups * n_splits * pgroups;
+    const int64_t worker = (int64_t)blockIdx.x * SCORE_WAVES + wave, workers = (int64_t)gridDim.x * SCORE_WAVES;
 
     for (int64_t task = worker; task < n_tasks; task += workers) {
         const int pg = (int)(task % pgroups);
         const int64_t rest = task / pgroups;
-        const int split = (int)(rest % splits_here) * classes + xcd, grp = (int)(rest / splits_here);
+        const int split = (int)(rest % n_splits), grp = (int)(rest / n_splits);
         const int p = pg * 8 + r;
         const int pc = p < n_perm ? p : n_perm - 1;
         const int64_t c0 = (int64_t)split * cells_per_split;
