@@ -61,7 +61,7 @@ int sc_ctx_reset_timers(sc_ctx *ctx);
 /* Enable/disable per-launch HIP-event timing (default on; events are recorded on the ctx stream). */
 int sc_ctx_set_timing(sc_ctx *ctx, int enabled);
 int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
-/* Development aid (scripts/concurrency_probe*.py): raw bytes of one of the generator's device buffers
+/* Development aid (scripts/concurrency_probe4.py, scripts/pipeline_soak.py): raw bytes of one of the generator's device buffers
  * (0 J, 1 raw stream, 2 accept masks, 3 entering counts, 4 block states, 5 scan state, 6 table, 7 inverse table). */
 int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64_t bytes);
 /* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values,

@@ -140,10 +140,6 @@ int sc_ctx_create(int device, sc_ctx **out)
     sc_ctx *c = new sc_ctx();
     c->device = device;
     if (getenv("SC_LOCAL_MORAN_DIRECT")) c->lm_direct = true;  // development: A/B of the per-cell count kernels
-    if (const char *v = getenv("SC_MORAN_VARIANT")) {  // development: A/B the scoring kernels on one box
-        const int k = atoi(v);
-        if (k >= 1 && k <= 2) c->moran_variant = k;
-    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

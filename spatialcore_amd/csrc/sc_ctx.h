@@ -109,7 +109,6 @@ struct sc_ctx {
                          // [tile32][cell][32] float (float32-exact values) or [tile64][cell][64] uint16 (counts < 65536)
     bool x32_valid = false, x32_exact = false;  // the narrow copy was (tried to be) built / is usable
     int narrow_bits = 64;                       // ... and its element width: 16, 32 (64: none, fp64 tiles only)
-    int moran_variant = 1;      // persistent scoring kernel: 1 = 4 cells per pipeline stage, 2 = 8 (SC_MORAN_VARIANT; development)
     int n_cus = 0;              // compute units of the device (filled on first use)
     int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
     int source_bits_min = 16;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)

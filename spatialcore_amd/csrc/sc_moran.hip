@@ -956,8 +956,8 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         if ((int64_t)wgs * SCORE_WAVES > tasks) wgs = (int)ceil_div64(tasks, SCORE_WAVES);
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
-            auto kern = bits == 16 ? (c->moran_variant == 2 ? k_moran_score<16, 8> : k_moran_score<16, 4>)
-                                   : (c->moran_variant == 2 ? k_moran_score<32, 8> : k_moran_score<32, 4>);
+            // (8 cells per stage were measured too: under the 128-VGPR cap of the 1024-thread form they spill)
+            auto kern = bits == 16 ? k_moran_score<16, 4> : k_moran_score<32, 4>;
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, c->X32.as<uint4>(),
                                c->Lag.as<double>(), (int64_t)tile_elems, (int)T, c->g_mean.as<double>(),
                                c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), n, c->p_stride, cnt, cps,
