@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256) void k_radius(const double *__restrict__ sx, c
     const int xlo = bx - rings < 0 ? 0 : bx - rings, xhi = bx + rings >= nbx ? nbx - 1 : bx + rings;
     long long cnt = 0;
     int32_t *row = FILL ? indices + indptr[qid] : nullptr;
+    // short rows are kept ascending by insertion; long ones (large radii) are appended and heap-sorted at the end:
+    // insertion in global memory is O(degree^2) writes
+    const bool by_insertion = FILL ? (indptr[qid + 1] - indptr[qid] <= 32) : true;
     for (int yy = ylo; yy <= yhi; ++yy) {
         const int s0 = bin_start[yy * nbx + xlo], s1 = bin_start[yy * nbx + xhi + 1];
         for (int s = s0; s < s1; ++s) {
@@ -304,9 +307,9 @@ __global__ __launch_bounds__(256) void k_radius(const double *__restrict__ sx, c
             const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
             if (cid != qid && d <= r2) {
                 if (FILL) {
-                    // insertion keeps the row ascending by index
                     long long j = cnt;
-                    while (j > 0 && row[j - 1] > cid) { row[j] = row[j - 1]; --j; }
+                    if (by_insertion)
+                        while (j > 0 && row[j - 1] > cid) { row[j] = row[j - 1]; --j; }
                     row[j] = cid;
                 }
                 ++cnt;
@@ -314,6 +317,23 @@ __global__ __launch_bounds__(256) void k_radius(const double *__restrict__ sx, c
         }
     }
     if (!FILL) counts[qid] = cnt;
+    if (FILL && !by_insertion) {   // in-place heapsort, ascending
+        auto sift = [&](long long root, long long end) {
+            for (;;) {
+                long long child = 2 * root + 1;
+                if (child >= end) break;
+                if (child + 1 < end && row[child] < row[child + 1]) ++child;
+                if (row[root] >= row[child]) break;
+                const int32_t tmp = row[root]; row[root] = row[child]; row[child] = tmp;
+                root = child;
+            }
+        };
+        for (long long k = cnt / 2 - 1; k >= 0; --k) sift(k, cnt);
+        for (long long end = cnt - 1; end > 0; --end) {
+            const int32_t tmp = row[0]; row[0] = row[end]; row[end] = tmp;
+            sift(0, end);
+        }
+    }
 }
 
 extern "C" int sc_radius_count_2d(sc_ctx *c, const double *xy, int64_t n, double radius, int64_t *indptr_out)

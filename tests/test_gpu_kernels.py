@@ -173,7 +173,7 @@ def test_reference_weights_golden(ctx):
         np.testing.assert_array_equal(data.astype(np.float32), g[f"c{ci}_W_data"])
 
 
-@pytest.mark.parametrize("radius", [12.0, 30.0])
+@pytest.mark.parametrize("radius", [12.0, 30.0, 75.0])   # ~11, ~70 (heap-sorted rows), ~440 neighbours
 def test_radius_graph(ctx, oracle, radius):
     rng = np.random.default_rng(9)
     xy = rng.uniform(0, 400, (4000, 2))
