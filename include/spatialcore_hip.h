@@ -65,10 +65,11 @@ int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
  * (0 J, 1 raw stream, 2 accept masks, 3 entering counts, 4 block states, 5 scan state, 6 table, 7 inverse table). */
 int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64_t bytes);
 /* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values,
- * one 128-byte row per cell and gene group: uint16 when every value is an integer count in [0, 65535] (64 genes per
- * row), else float32 when every value is a float32 (32 genes), else the fp64 tiles (16 genes).
- * z = (double)x - mean is rebuilt in registers, so all three give the same z and -- same cell order -- the same sums.
- * min_bits (16, 32 or 64; default 16) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
+ * one 128-byte row per cell and gene group: uint8 when every value is an integer count in [0, 255] (128 genes per
+ * row), uint16 for counts up to 65535 (64 genes), else float32 when every value is a float32 (32 genes), else the fp64
+ * tiles (16 genes).  The uint16 / float32 kernels rebuild z = (double)x - mean in registers (same z, same sums as the
+ * fp64 tiles up to summation order); the uint8 kernel sums lag * x and subtracts mean * sum(lag) once per statistic.
+ * min_bits (8, 16, 32 or 64; default 8) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
  * scoring call used (64 = the general fp64 kernel). */
 int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
 int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);

@@ -213,12 +213,13 @@ class Context:
         _check(self._lib.sc_ctx_set_permgen_mode(self._h, int(mode)))
 
     def set_moran_source_bits(self, min_bits: int) -> None:
-        """Narrowest exact source copy the permutation kernels may gather: 16 (default: uint16 when every value is
-        an integer count < 65536), 32 (float32) or 64 (the fp64 tiles)."""
+        """Narrowest exact source copy the permutation kernels may gather: 8 (default: uint8 when every value is an
+        integer count < 256), 16 (uint16, counts < 65536), 32 (float32) or 64 (the fp64 tiles)."""
         _check(self._lib.sc_ctx_set_moran_source_bits(self._h, int(min_bits)))
 
     def moran_source_bits(self) -> int:
-        """Source width the last scoring call gathered: 16 (uint16 counts), 32 (float32 raw values) or 64 (fp64 kernel)."""
+        """Source width the last scoring call gathered: 8 / 16 (uint8 / uint16 counts), 32 (float32 raw values) or
+        64 (fp64 kernel)."""
         v = c_int(0)
         _check(self._lib.sc_ctx_moran_source_bits(self._h, byref(v)))
         return v.value

@@ -106,15 +106,16 @@ struct sc_ctx {
     int e_dtype = SC_F64;  // dtype of the matrix the tiles were loaded from (the reference's float32 paths depend on it)
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // the raw values again in the narrowest exact type, one 128-byte row per cell and gene group:
-                         // [tile32][cell][32] float (float32-exact values) or [tile64][cell][64] uint16 (counts < 65536)
+                         // 32 float (float32-exact values), 64 uint16 (counts < 65536) or 128 uint8 (counts < 256) per row
     bool x32_valid = false, x32_exact = false;  // the narrow copy was (tried to be) built / is usable
-    int narrow_bits = 64;                       // ... and its element width: 16, 32 (64: none, fp64 tiles only)
+    int narrow_bits = 64;                       // ... and its element width: 8, 16, 32 (64: none, fp64 tiles only)
     int n_cus = 0;              // compute units of the device (filled on first use)
     int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
-    int source_bits_min = 16;   // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
+    int source_bits_min = 8;    // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
     int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene
+    DBuf g_slag;         // uint8 source: [sum_j lag_g[j] | mean_g * that] per padded gene
 
     // ---- permutation table ----
     int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)

@@ -66,7 +66,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     int64_t tiles = ceil_div64(n_genes, SC_TILE);
     size_t bytes = (size_t)tiles * n * SC_TILE * sizeof(double);
     SC_TRY(c->X.ensure(bytes, &c->mem));
-    size_t gb = (size_t)align_up64(tiles, 4) * SC_TILE * sizeof(double);  // the 64-gene kernel reads 64 means
+    size_t gb = (size_t)align_up64(tiles, 8) * SC_TILE * sizeof(double);  // the narrow-source kernels read whole groups
     SC_TRY(c->g_mean.ensure(gb, &c->mem));
     SC_TRY(c->g_var.ensure(gb, &c->mem));
     SC_TRY(c->g_z2.ensure(gb, &c->mem));
@@ -528,7 +528,7 @@ template <int BITS>
 __global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ X, uint4 *__restrict__ out, int64_t n,
                                                      int64_t tiles16, int *__restrict__ inexact)
 {
-    constexpr int TG = BITS == 16 ? 4 : 2;
+    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : 2;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (cell, q)
     if (t >= n * 8) return;
     const int64_t cell = t >> 3;
@@ -540,7 +540,11 @@ __global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ 
         const int64_t t16 = TG * (int64_t)blockIdx.y + tt;
         if (t16 >= tiles16) continue;
         const double2 v = reinterpret_cast<const double2 *>(X + t16 * n * SC_TILE + cell * SC_TILE)[q];
-        if (BITS == 16) {
+        if (BITS == 8) {
+            const uint32_t a = (uint32_t)(v.x >= 0.0 && v.x <= 255.0 ? v.x : 0.0), b = (uint32_t)(v.y >= 0.0 && v.y <= 255.0 ? v.y : 0.0);
+            bad |= (double)a != v.x || (double)b != v.y;
+            o[tt >> 1] |= (a | (b << 8)) << (16 * (tt & 1));
+        } else if (BITS == 16) {
             const uint32_t a = (uint32_t)(v.x >= 0.0 && v.x <= 65535.0 ? v.x : 0.0), b = (uint32_t)(v.y >= 0.0 && v.y <= 65535.0 ? v.y : 0.0);
             bad |= (double)a != v.x || (double)b != v.y;   // NaN, negative, fractional or too large
             o[tt] = a | (b << 16);
@@ -620,8 +624,12 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
     int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
 {
-    static_assert((BITS == 16 || BITS == 32) && (CB == 4 || CB == 8), "source width / block size");
-    constexpr int TG = BITS == 16 ? 4 : 2;       // 16-gene lag tiles per gene group
+    static_assert((BITS == 8 || BITS == 16 || BITS == 32) && (CB == 4 || CB == 8), "source width / block size");
+    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : 2;   // 16-gene lag tiles per gene group
+    // BITS == 8 (128 genes per row, 16 accumulators per lane): no room for the 16 means in registers -- the raw values
+    // are multiplied as they are, sum_j lag[j] * x[inv[j]], and mean * sum_j lag[j] is taken off in the finalisation
+    // (the same number up to rounding: |mean| / sd <= ~16 for counts <= 255, i.e. ~1e-12 relative on the sums)
+    constexpr bool CENTER = BITS != 8;
     constexpr int ROW = TG * 8;                  // 16-byte pieces of a group's lag row (one cell)
     constexpr int NI = CB / 4;                   // index vectors per block
     constexpr int NL = CB * ROW / 64;            // lag pieces per lane and block
@@ -656,11 +664,13 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
         const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
         // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
         const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (lane & 7);
-        double m[TG][2], acc[TG][2];
+        double m[CENTER ? TG : 1][2], acc[TG][2];
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
-            const double *mt = mean + (int64_t)(TG * grp + (t < tiles_left ? t : 0)) * SC_TILE + 2 * q;
-            m[t][0] = mt[0]; m[t][1] = mt[1];
+            if constexpr (CENTER) {
+                const double *mt = mean + (int64_t)(TG * grp + (t < tiles_left ? t : 0)) * SC_TILE + 2 * q;
+                m[t][0] = mt[0]; m[t][1] = mt[1];
+            }
             acc[t][0] = acc[t][1] = 0.0;
         }
         const int64_t nblk = (c1 - c0) / CB;
@@ -702,10 +712,14 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
             for (int t = 0; t < TG; ++t) {
                 const double2 l = lr[t * 8];
                 double v0, v1;
-                if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                if (BITS == 8) {
+                    const uint32_t h = w[t >> 1] >> (16 * (t & 1));
+                    v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
+                } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
                 else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
-                acc[t][0] = fma(l.x, v0 - m[t][0], acc[t][0]);
-                acc[t][1] = fma(l.y, v1 - m[t][1], acc[t][1]);
+                if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
+                acc[t][0] = fma(l.x, v0, acc[t][0]);
+                acc[t][1] = fma(l.y, v1, acc[t][1]);
             }
         };
         auto multiply = [&](const uint4 (&x)[CB], int buf) {
@@ -748,10 +762,14 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
             for (int t = 0; t < TG; ++t) {
                 const double2 l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
                 double v0, v1;
-                if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                if (BITS == 8) {
+                    const uint32_t h = w[t >> 1] >> (16 * (t & 1));
+                    v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
+                } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
                 else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
-                acc[t][0] = fma(l.x, v0 - m[t][0], acc[t][0]);
-                acc[t][1] = fma(l.y, v1 - m[t][1], acc[t][1]);
+                if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
+                acc[t][0] = fma(l.x, v0, acc[t][0]);
+                acc[t][1] = fma(l.y, v1, acc[t][1]);
             }
         }
         if (p < n_perm) {
@@ -765,9 +783,11 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
 
 // sims[p0 + p][GP grp + slot] = scale * sum_s partial[grp][s][p][slot] (ascending s), for every gene group of a
 // chunk in one launch (GP = genes per group: 64 for the uint16 source, 32 for float32)
+// (corr != nullptr: the uint8 kernel summed lag * x, not lag * (x - mean): corr[g] = mean[g] * sum_j lag_g[j] is taken off)
 template <int GP>
 __global__ __launch_bounds__(256) void k_moran_finalize_groups(const double *__restrict__ partial,
                                                                const double *__restrict__ scale,
+                                                               const double *__restrict__ corr,
                                                                double *__restrict__ sims, int n_perm, int splits,
                                                                int64_t n_genes, int64_t p0)
 {
@@ -778,7 +798,15 @@ __global__ __launch_bounds__(256) void k_moran_finalize_groups(const double *__r
     const double *pt = partial + (int64_t)blockIdx.y * splits * n_perm * GP;
     double s = 0.0;
     for (int k = 0; k < splits; ++k) s += pt[((int64_t)k * n_perm + p) * GP + slot];
+    if (corr) s -= corr[g];
     sims[(p0 + p) * n_genes + g] = scale[g] * s;
+}
+
+// corr[g] = mean[g] * slag[g]
+__global__ void k_mean_times(const double *__restrict__ mean, const double *__restrict__ slag, double *__restrict__ corr, int64_t total)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < total) corr[g] = mean[g] * slag[g];
 }
 
 // cell range of one scoring task: a function of n ALONE (results must not depend on the chunking of the
@@ -836,26 +864,24 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm)
         int64_t cps = 0;
         const int splits64 = pick_splits(n, 1, &cps);  // upper bound on the fp64 kernel's split count
         const int64_t score_splits = ceil_div64(n, score_cells_per_split(n));
-        const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 64);
+        const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
         const size_t wide_rows = (size_t)splits64 * SC_TILE;
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
         if (!c->x32_valid) {
             // the narrowest EXACT copy of the raw values the caller allows: uint16 (64 genes per 128-byte row) for
             // count data, else float32 (32 genes per row), else none (fp64 tiles, 16 genes per row)
-            const int64_t T32 = (T + 1) / 2, T64 = (T + 3) / 4;
-            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= T64 * n * 128 bytes
+            const int64_t T32 = (T + 1) / 2;
+            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= the uint16 / uint8 copies
             SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
             c->narrow_bits = 64;
-            for (int bits = c->source_bits_min <= 16 ? 16 : 32; bits <= 32 && c->narrow_bits == 64 && c->source_bits_min <= 32;
-                 bits += 16) {
+            for (int bits = 8; bits <= 32 && c->narrow_bits == 64; bits *= 2) {
+                if (bits < c->source_bits_min) continue;
                 SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
-                const dim3 grid((unsigned)ceil_div64(n * 8, 256), (unsigned)(bits == 16 ? T64 : T32));
-                if (bits == 16)
-                    hipLaunchKernelGGL(k_pack_narrow<16>, grid, dim3(256), 0, c->stream, c->X.as<double>(),
-                                       c->X32.as<uint4>(), n, T, c->perm_flag.as<int>());
-                else
-                    hipLaunchKernelGGL(k_pack_narrow<32>, grid, dim3(256), 0, c->stream, c->X.as<double>(),
-                                       c->X32.as<uint4>(), n, T, c->perm_flag.as<int>());
+                const int tg = bits == 8 ? 8 : bits == 16 ? 4 : 2;
+                const dim3 grid((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, tg));
+                auto pack = bits == 8 ? k_pack_narrow<8> : bits == 16 ? k_pack_narrow<16> : k_pack_narrow<32>;
+                hipLaunchKernelGGL(pack, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T,
+                                   c->perm_flag.as<int>());
                 int inexact = 0;
                 SC_HIP(hipMemcpyAsync(&inexact, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 SC_HIP(hipStreamSynchronize(c->stream));
@@ -863,6 +889,15 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm)
             }
             c->x32_exact = c->narrow_bits < 64;
             c->x32_valid = true;
+        }
+        if (c->x32_exact && c->narrow_bits == 8) {   // the uint8 kernel's correction term mean * sum(lag), per gene
+            const size_t gb = (size_t)align_up64(T, 8) * SC_TILE * sizeof(double);
+            SC_TRY(c->g_slag.ensure(2 * gb, &c->mem));
+            double *slag = c->g_slag.as<double>(), *corr = slag + align_up64(T, 8) * SC_TILE;
+            SC_TRY(colsum<OP_ID>(c, c->Lag.as<double>(), nullptr, slag, 1.0));
+            hipLaunchKernelGGL(k_mean_times, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
+                               c->g_mean.as<double>(), slag, corr, T * SC_TILE);
+            SC_HIP(hipGetLastError());
         }
     }
     return SC_OK;
@@ -941,7 +976,7 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         SC_REQUIRE(n < ((int64_t)1 << 25), SC_ERR_INVALID, "the narrow-source scoring kernel addresses rows with 32-bit "
                    "byte offsets: n_cells must be < 2^25 (got %lld); use sc_ctx_set_moran_source_bits(ctx, 64)", (long long)n);
         if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
-        const int GP = bits == 16 ? 64 : 32;
+        const int GP = bits == 8 ? 128 : bits == 16 ? 64 : 32;
         const int groups = (int)ceil_div64(T * SC_TILE, GP);
         const int64_t cps = score_cells_per_split(n);
         const int splits = (int)ceil_div64(n, cps);
@@ -957,20 +992,24 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
             // (8 cells per stage were measured too: under the 128-VGPR cap of the 1024-thread form they spill)
-            auto kern = bits == 16 ? k_moran_score<16, 4> : k_moran_score<32, 4>;
+            auto kern = bits == 8 ? k_moran_score<8, 4> : bits == 16 ? k_moran_score<16, 4> : k_moran_score<32, 4>;
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, c->X32.as<uint4>(),
                                c->Lag.as<double>(), (int64_t)tile_elems, (int)T, c->g_mean.as<double>(),
                                c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), n, c->p_stride, cnt, cps,
                                splits, groups);
         }
-        if (bits == 16)
-            hipLaunchKernelGGL(k_moran_finalize_groups<64>, dim3((unsigned)ceil_div64((int64_t)cnt * 64, 256), (unsigned)groups),
-                               dim3(256), 0, c->stream, c->partial.as<double>(), c->g_scale.as<double>(),
+        const dim3 fgrid((unsigned)ceil_div64((int64_t)cnt * GP, 256), (unsigned)groups);
+        const double *no_corr = nullptr;
+        if (bits == 8)
+            hipLaunchKernelGGL(k_moran_finalize_groups<128>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
+                               c->g_scale.as<double>(), c->g_slag.as<double>() + align_up64(T, 8) * SC_TILE,
                                c->sims.as<double>(), cnt, splits, G, p0);
+        else if (bits == 16)
+            hipLaunchKernelGGL(k_moran_finalize_groups<64>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
+                               c->g_scale.as<double>(), no_corr, c->sims.as<double>(), cnt, splits, G, p0);
         else
-            hipLaunchKernelGGL(k_moran_finalize_groups<32>, dim3((unsigned)ceil_div64((int64_t)cnt * 32, 256), (unsigned)groups),
-                               dim3(256), 0, c->stream, c->partial.as<double>(), c->g_scale.as<double>(),
-                               c->sims.as<double>(), cnt, splits, G, p0);
+            hipLaunchKernelGGL(k_moran_finalize_groups<32>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
+                               c->g_scale.as<double>(), no_corr, c->sims.as<double>(), cnt, splits, G, p0);
         SC_HIP(hipGetLastError());
         return SC_OK;
     }

@@ -166,7 +166,7 @@ def test_pipeline_is_exact_next_to_other_kernels_at_bench_size(big):
         ctx.graph_from_knn(1.0 / K)
         w = _lib.rng_state_words(np.random.default_rng(0))
         out = ctx.moran_seeded(w, P)
-        assert ctx.moran_source_bits() == 16                      # Poisson counts: uint16 source
+        assert ctx.moran_source_bits() == 8                       # small Poisson counts: uint8 source
         np.testing.assert_array_equal(w, wh, err_msg=f"generator state, repetition {rep}")
         bad = np.flatnonzero((out["sims"] != ref["sims"]).any(axis=1))
         assert bad.size == 0, f"repetition {rep}: {bad.size} permutations differ, first {bad[:5].tolist()}"
@@ -266,7 +266,7 @@ def test_config4_shape_5m_cells_indexing():
         P2 = 400
         w = _lib.rng_state_words(np.random.default_rng(3))
         one = ctx.moran_seeded(w, P2)
-        assert ctx.permgen_stats()[2] == 0 and ctx.moran_source_bits() == 16
+        assert ctx.permgen_stats()[2] == 0 and ctx.moran_source_bits() == 8
         wh = _lib.rng_state_words(np.random.default_rng(3))
         last = _lib.perm_numpy_host(wh, n, P2)[P2 - 1].copy()
         np.testing.assert_array_equal(w, wh)

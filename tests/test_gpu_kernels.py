@@ -272,7 +272,7 @@ def test_moran_seeded_bench_schedule_p1000_vs_oracle(ctx, oracle, n, G, seed):
     w = rng_state_words(np.random.default_rng(seed))
     before = ctx.permgen_stats()
     out = ctx.moran_seeded(w, P)
-    assert ctx.moran_source_bits() == 16                                # count data: uint16 source, 64 genes per row
+    assert ctx.moran_source_bits() == 8                                 # small counts: uint8 source, 128 genes per row
     assert ctx.permgen_stats()[2] == before[2]                         # no silent verification fallback
     np.testing.assert_array_equal(w, oracle.perm_table(seed, n, P)[1])  # generator state after P permutations
     np.testing.assert_allclose(out["I"], tab["I"], rtol=1e-9, atol=1e-14)
@@ -297,7 +297,7 @@ def test_moran_seeded_bench_schedule_block_parallel_generator(ctx, oracle):
     before = ctx.permgen_stats()
     one = ctx.moran_seeded(w, P)
     par, seq, fallbacks = (a - b for a, b in zip(ctx.permgen_stats()[:3], before[:3]))
-    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 16
+    assert (par, seq, fallbacks) == (1, 0, 0) and ctx.moran_source_bits() == 8
     # the oracle's own generator (scalar C model of numpy's stream) supplies the table of the two-step run
     cols = [0, 17, 32]
     conn = csr_matrix((np.ones(n * k), oracle.knn_tree(coords, k).reshape(-1), np.arange(0, n * k + 1, k)), shape=(n, n))
@@ -331,7 +331,7 @@ def test_moran_seeded_inverse_only_tables(ctx, oracle):
     two = ctx.moran(P)
     w2 = rng_state_words(np.random.default_rng(11))
     one = ctx.moran_seeded(w2, P)
-    assert ctx.moran_source_bits() == 16
+    assert ctx.moran_source_bits() == 8
     np.testing.assert_array_equal(w1, w2)
     for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
         np.testing.assert_array_equal(one[key], two[key], err_msg=key)
@@ -354,12 +354,13 @@ def test_moran_seeded_inverse_only_tables(ctx, oracle):
     np.testing.assert_array_equal(lee["L_perm"], lee2["L_perm"])
 
 
-@pytest.mark.parametrize("G", [5, 32, 47, 70, 131])
+@pytest.mark.parametrize("G", [5, 32, 47, 70, 131, 260])
 def test_moran_source_widths_agree(ctx, oracle, G):
-    """The permutation kernels gather the narrowest EXACT copy of the raw values: uint16 (64 genes per 128-byte row)
-    for integer counts < 65536, else float32 (32 genes) when every value is one, else the fp64 tiles (16).  All rebuild
-    the same z; the uint16 and float32 kernels add the same products in the same order (bit-identical), the fp64
-    kernel sums in another order (1e-9).  A kernel for a narrower type is refused when the values do not fit."""
+    """The permutation kernels gather the narrowest EXACT copy of the raw values: uint8 (128 genes per 128-byte row) for
+    integer counts < 256, uint16 (64 genes) for counts < 65536, else float32 (32 genes) when every value is one, else
+    the fp64 tiles (16).  The uint16 and float32 kernels rebuild the same z and add the same products in the same order
+    (bit-identical); the fp64 kernel sums in another order, and the uint8 kernel sums lag * x and takes mean * sum(lag)
+    off afterwards (1e-9 both).  A kernel for a narrower type is refused when the values do not fit."""
     from spatialcore_amd._lib import rng_state_words
 
     n, k, P = 3000, 6, 37
@@ -369,39 +370,53 @@ def test_moran_source_widths_agree(ctx, oracle, G):
     ctx.graph_from_knn(1.0 / k)
     out = {}
     try:
-        for bits in (16, 32, 64):
+        for bits in (8, 16, 32, 64):
             ctx.set_moran_source_bits(bits)
             ctx.set_expression(X, np.arange(G))
             w = rng_state_words(np.random.default_rng(3))
             out[bits] = ctx.moran_seeded(w, P)
             assert ctx.moran_source_bits() == bits
-        ctx.set_moran_source_bits(16)
-        for Xd, want in ((X + np.float32(0.5), 32),                # fractional float32 values: no uint16 copy
+        ctx.set_moran_source_bits(8)
+        for Xd, want in ((X + np.float32(250.0), 16),              # counts beyond 255: no uint8 copy
+                         (X + np.float32(0.5), 32),                # fractional float32 values: no uint16 copy
                          (np.where(X == 0, -1, X).astype(np.float32), 32),   # negative
                          (X * np.float32(70000.0), 32),                    # beyond 65535 (still float32-exact)
                          (X.astype(np.float64) + 1e-9, 64)):       # float64 values that are not float32
             ctx.set_expression(Xd, np.arange(G))
             ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
             assert ctx.moran_source_bits() == want
-        big = X.copy(); big[7, G - 1] = 65535.0                    # the largest count that still fits
-        ctx.set_expression(big, np.arange(G))
-        edge = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
-        assert ctx.moran_source_bits() == 16
+        for top, want in ((255.0, 8), (65535.0, 16)):              # the largest counts that still fit
+            big = X.copy(); big[7, G - 1] = top
+            ctx.set_moran_source_bits(8)
+            ctx.set_expression(big, np.arange(G))
+            edge = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
+            assert ctx.moran_source_bits() == want
+            ctx.set_moran_source_bits(64)
+            ctx.set_expression(big, np.arange(G))
+            edge64 = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
+            np.testing.assert_allclose(edge["sims"], edge64["sims"], rtol=1e-9, atol=1e-13)
+        dense = np.full_like(X, 255.0); dense[::3] = 254.0; dense[:, 1::2] = X[:, 1::2]   # mean / sd at its worst
+        ctx.set_moran_source_bits(8)
+        ctx.set_expression(dense, np.arange(G))
+        hard = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 5)
+        assert ctx.moran_source_bits() == 8
         ctx.set_moran_source_bits(64)
-        ctx.set_expression(big, np.arange(G))
-        edge64 = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 3)
-        np.testing.assert_allclose(edge["sims"], edge64["sims"], rtol=1e-9, atol=1e-13)
+        ctx.set_expression(dense, np.arange(G))
+        hard64 = ctx.moran_seeded(rng_state_words(np.random.default_rng(3)), 5)
+        np.testing.assert_allclose(hard["sims"], hard64["sims"], rtol=1e-9, atol=1e-13)
     finally:
-        ctx.set_moran_source_bits(16)
+        ctx.set_moran_source_bits(8)
     for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
         np.testing.assert_array_equal(out[16][key], out[32][key], err_msg=key)     # bit-identical
     np.testing.assert_array_equal(out[32]["I"], out[64]["I"])
+    np.testing.assert_array_equal(out[8]["I"], out[64]["I"])
     np.testing.assert_allclose(out[32]["sims"], out[64]["sims"], rtol=1e-9, atol=1e-13)
-    np.testing.assert_allclose(out[16]["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
-    np.testing.assert_allclose(out[16]["I"], tab["I"], rtol=1e-9, atol=1e-14)
-    assert_counts_match(out[16]["count_ge"], tab["sims"], tab["I"])
+    for bits in (8, 16):
+        np.testing.assert_allclose(out[bits]["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(out[bits]["I"], tab["I"], rtol=1e-9, atol=1e-14)
+        assert_counts_match(out[bits]["count_ge"], tab["sims"], tab["I"])
     with pytest.raises(ValueError):
-        ctx.set_moran_source_bits(8)
+        ctx.set_moran_source_bits(12)
 
 
 def test_moran_gene_subset_and_uploaded_perms(ctx, oracle):
