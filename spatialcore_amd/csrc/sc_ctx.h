@@ -127,6 +127,7 @@ struct sc_ctx {
     bool perm_bijective = false;   // the active table is known to hold true permutations
     bool perm_checked = false;     // ... or was checked and is not
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
+    DBuf pg_flags;       // hand-over words between the chain workgroup and the preparation launches (sc_permgen.hip)
     DBuf pg_desc, pg_tbits, pg_events, pg_hard;  // block-parallel scan: per-block descriptors + gap-transfer tables (ring), hard flags
 
     // ---- Moran / Lee work buffers ----

@@ -1230,7 +1230,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
 }
 
 #ifndef SCORE_RESERVED_CUS
-#define SCORE_RESERVED_CUS 32
+#define SCORE_RESERVED_CUS 64
 #endif
 // SCORE_RESERVED_CUS: compute units the persistent scoring kernel leaves EMPTY for the generator that runs beside it.
 //
@@ -1239,8 +1239,11 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
 // that must not queue behind them.  r01 kept them apart with CU-masked and prioritised streams; r02 does it by the
 // scoring kernel's own shape -- a grid of (CUs - reserved) one-per-CU workgroups (see k_moran_score) on plain streams,
 // each stream on its own hardware queue (GPU_MAX_HW_QUEUES, see sc_api.hip).  Measured on one box, 1M cells x 500
-// genes x 1000 permutations: reserved 16 -> 1406 genes/s, 32 -> 1716, 48 -> no better; with the runtime's default
-// of 4 shared hardware queues 1174 (the chain's launches queue behind 25-ms scoring launches).
+// genes x 1000 permutations, uint16 source, event-ordered generator: reserved 16 -> 1406 genes/s, 32 -> 1716, 48 -> no
+// better; with the runtime's default of 4 shared hardware queues 1174 (the chain's launches queue behind 25-ms scoring
+// launches).  With the uint8 source and the flag-ordered generator (one chain launch per chunk; its gate / publish
+// launches need free wavefront slots at once): 32 -> 2050, 40 / 48 -> 2177, 64 -> 2327, 72 -> 2332, 80 -> 2302,
+// 96 -> 2347, 128 -> 2173 (scoring 125 ms on 224 CUs, 157 on 192, 190 on 128: the step is balanced around 64-96).
 static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
                                 int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
 {
@@ -1248,6 +1251,7 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
     int leave = c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n) ? SCORE_RESERVED_CUS : 8;
     if (const char *v = getenv("SC_SCORE_LEAVE_CUS")) leave = atoi(v);  // development: sweep the reservation
     c->pg_ahead = PIPE_AHEAD;
+    if (const char *v = getenv("SC_PIPE_AHEAD")) c->pg_ahead = atoi(v);  // development: sweep the lookahead
     c->score_leave_cus = leave;
     const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
     c->score_leave_cus = 0;

@@ -478,10 +478,6 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
                                   // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
 #define PHI_RING 2048             // table ring slots (> PHI_AHEAD_MAX + 2 units)
 #define PHI_STREAMS 4             // preparation streams (units rotate over them)
-#ifndef PHI_GROUP
-#define PHI_GROUP 1               // launch units chained by one k_chain launch (measured in the pipeline: 2 -> -1.3 %,
-                                  // 4 -> -18 %: the launch has to wait for the preparation of all its units)
-#endif
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
 
 static_assert((PHI_AHEAD_MAX + 1) * PHI_UNIT <= PHI_RING, "a unit's ring slots are reused only after the chain consumed them");
@@ -719,6 +715,43 @@ __device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hand-over words between the chain workgroup and the preparation launches (r02).
+//
+// r01 ordered "preparation of unit u -> chain of unit u -> preparation of unit u + ahead + 1" with events: one chain
+// launch per unit, a barrier packet in front of it and a marker behind it -- 0.21 ms of idle chain stream per unit
+// (37 of 232 ms per bench step).  Now ONE chain launch runs a whole chunk of permutations and both directions are words
+// in device memory:  flags[1 + u % 16] = u + 1 once unit u is prepared (k_publish, behind the unit's preparation
+// launches in their stream), flags[0] = number of units the chain has completed (k_chain, after each unit; the
+// preparation of unit u starts behind k_gate, one wavefront that waits for flags[0] >= u - ahead).
+// Every wait gives up after 10 s or when a failure flag is up (e.g. when the streams do not run concurrently: a
+// profiler that serialises kernels, fewer hardware queues than streams) and raises flag 8 / 16: the caller then
+// reruns the job with the sequential scan, as after a failed verification.
+// ------------------------------------------------------------------------------------------------
+#define PHI_FLAG_SLOTS 16
+#define PHI_WAIT_TICKS 1000000000ll   // 10 s of the 100 MHz wall clock (a chunk of 128 permutations of 3 x 10^7 cells takes ~1 s)
+
+__device__ __forceinline__ bool phi_wait_at_least(const uint32_t *flag, uint32_t want, const unsigned long long *st)
+{
+    const long long t0 = wall_clock64();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        if (__hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return false;
+        if (wall_clock64() - t0 > PHI_WAIT_TICKS || spins > (1u << 28)) return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+__global__ void k_publish(uint32_t *flags, uint32_t slot, uint32_t value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flags + slot, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_gate(const uint32_t *flags, uint32_t chain_units_needed, unsigned long long *st)
+{
+    if (threadIdx.x == 0 && !phi_wait_at_least(flags, chain_units_needed, st)) atomicOr(st + 2, 16ull);
+}
+
 // Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
 // wavefront 0, the others the full in-block fixed point.  While a block is computed, the draws of the next
 // block to compute and the tables of the run of prepared blocks before it are already on their way (registers,
@@ -731,9 +764,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                                                         uint8_t *__restrict__ hardmask, int fault,
                                                         bits_t *__restrict__ acc_bits, uint32_t *__restrict__ enter,
                                                         unsigned long long *__restrict__ sblk,
-                                                        unsigned long long *__restrict__ st)
+                                                        unsigned long long *__restrict__ st, uint32_t *__restrict__ flags,
+                                                        uint32_t unit0)
 {
     __shared__ BlockShared sh;
+    __shared__ uint32_t shReady;
     __shared__ PhiDesc dsc[PHI_UNIT];
     __shared__ uint16_t nxt[PHI_UNIT + 2];  // first block >= i (relative to b0) the chain computes itself
     __shared__ unsigned long long shS, shB;
@@ -742,7 +777,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
     const uint32_t M = n - 1, top_mask = mask_of(M);
     uint64_t S = st[0];
-    if (S >= total_steps || st[1] != B0 || B1 > n_blocks) return;  // job complete (uniform)
+    if (S >= total_steps || st[1] != B0 || B1 > n_blocks) {  // job complete, or an earlier launch gave up (uniform)
+        if (tau == 0) __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // no gate waits for us
+        return;
+    }
     uint32_t parity = 0;
     int failed = 0;
     uint64_t endpos = 0;
@@ -750,10 +788,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
     uint64_t b_next = B0;
     // one launch chains several launch units (each prepared by its own launches; the host waited for all of them)
-    for (uint64_t b0 = B0; b0 < B1 && !failed && S < total_steps; b0 += PHI_UNIT) {
+    uint32_t unit = unit0;
+    int gave_up = 0;
+    for (uint64_t b0 = B0; b0 < B1 && !failed && S < total_steps; b0 += PHI_UNIT, ++unit) {
     const uint64_t b1 = b0 + PHI_UNIT < B1 ? b0 + PHI_UNIT : B1;
     const uint32_t nb = (uint32_t)(b1 - b0);
     __syncthreads();  // the previous unit's readers of dsc / nxt / tl are done
+    if (tau == 0) shReady = phi_wait_at_least(flags + 1 + unit % PHI_FLAG_SLOTS, unit + 1, st) ? 1u : 0u;
+    __syncthreads();
+    if (!shReady) { gave_up = 1; break; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the unit's descriptors and tables, written by other kernels
     if (tau < nb) dsc[tau] = desc[(b0 + tau) % PHI_RING];
     __syncthreads();
     if (tau <= nb) {
@@ -844,6 +888,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         if (S >= total_steps) break;
     }
     b_next = b0 + rel;
+    if (tau == 0) {  // entry state of the next unit (the reference of a later unit's guesses), then "unit done"
+        sblk[b_next] = S;
+        __hip_atomic_store(flags, unit + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }  // units
 #undef PHI_STAGE_LOAD
     if (endpos) st[3] = endpos;
@@ -856,8 +904,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
         unsigned long long f = 0;  // (k_block_exact of the previous chunk may be raising its own flag right now)
         if (failed) f |= 1ull;
+        if (gave_up) f |= 8ull;  // a unit's preparation did not arrive
         if (S < S_need && S < total_steps) f |= 2ull;  // the blocks granted to this chunk did not complete it
         if (f) atomicOr(st + 2, f);
+        if (f || S >= total_steps)  // nothing more will come from the chain: release every gate
+            __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1110,6 +1161,8 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
             st0[0] = 1;
         }
     }
+    SC_TRY(c->pg_flags.ensure(sizeof(uint32_t) * (1 + PHI_FLAG_SLOTS), &c->mem));
+    SC_HIP(hipMemsetAsync(c->pg_flags.p, 0, sizeof(uint32_t) * (1 + PHI_FLAG_SLOTS), s));
     SC_HIP(hipMemcpyAsync(c->pg_out.p, st0, sizeof(st0), hipMemcpyHostToDevice, s));
     SC_HIP(hipMemcpyAsync(c->pg_sblk.p, st0, sizeof(unsigned long long), hipMemcpyHostToDevice, s));  // state at block 0
     SC_HIP(hipStreamSynchronize(s));  // st0 / j0 are stack variables
@@ -1144,45 +1197,38 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
         phi_first = job->B_done;
         phi_end = B_end;
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
+        // the chunk's launch units: each prepared by its own launches (4 rotating streams), all chained by ONE launch
+        const uint64_t g0 = job->B_done;
+        const int64_t u_first = job->unit_no;
+        uint32_t *flags = c->pg_flags.as<uint32_t>();
         while (job->B_done < B_end) {
-            // a group of launch units: each prepared by its own launches, chained by ONE launch
-            const uint64_t g0 = job->B_done;
-            const int64_t u_first = job->unit_no;
-            int in_group = 0;
-            while (job->B_done < B_end && in_group < PHI_GROUP) {
-                const uint64_t b0 = job->B_done;
-                const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
-                const int64_t u = job->unit_no;
-                hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
-                hipEvent_t ev_prep = c->pg_ev[(size_t)(u % 16)];
-                // The guess of unit u uses the exact state at the start of unit u - ahead, which the chain launch of
-                // unit u - ahead - 1 leaves; that launch also is the last reader of the ring slots unit u overwrites.
-                const int64_t dep = u - job->ahead - 1;
-                const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
-                if (dep >= 0) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[(size_t)(16 + dep % 16)], 0));
-                else SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
-                hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
-                                   c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0,
-                                   b1, ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
-                                   c->pg_events.as<uint16_t>());
-                hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
-                                   c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
-                                   c->pg_tbits.as<unsigned long long>());
-                SC_HIP(hipEventRecord(ev_prep, sp));
-                SC_HIP(hipStreamWaitEvent(s, ev_prep, 0));
-                job->unit_start[(size_t)(u % 8)] = b0;
-                job->B_done = b1;
-                job->unit_no = u + 1;
-                ++in_group;
-            }
-            const uint64_t g1 = job->B_done;
-            hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
-                               (uint32_t)job->n, job->total_steps, g0, g1, g1 == B_end ? target : 0ull,
-                               c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(),
-                               c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
-                               c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st);
-            for (int64_t u = u_first; u < job->unit_no; ++u) SC_HIP(hipEventRecord(c->pg_ev[(size_t)(16 + u % 16)], s));
+            const uint64_t b0 = job->B_done;
+            const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
+            const int64_t u = job->unit_no;
+            hipStream_t sp = c->stream_pg[(size_t)(u % PHI_STREAMS)];
+            // The guess of unit u uses the exact state at the start of unit u - ahead, which the chain leaves when it
+            // completes unit u - ahead - 1; that unit also is the last reader of the ring slots unit u overwrites.
+            const int64_t dep = u - job->ahead - 1;
+            const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
+            if (u < PHI_STREAMS) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
+            if (dep >= 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(dep + 1), st);
+            hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
+                               c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0,
+                               b1, ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
+                               c->pg_events.as<uint16_t>());
+            hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
+                               c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
+                               c->pg_tbits.as<unsigned long long>());
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(1 + u % PHI_FLAG_SLOTS), (uint32_t)(u + 1));
+            job->unit_start[(size_t)(u % 8)] = b0;
+            job->B_done = b1;
+            job->unit_no = u + 1;
         }
+        hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
+                           (uint32_t)job->n, job->total_steps, g0, B_end, target,
+                           c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(),
+                           c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
+                           c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st, flags, (uint32_t)u_first);
         SC_HIP(hipGetLastError());
     } else {
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
