@@ -12,11 +12,10 @@ for rep in range(3):
     ctx.generate_permutations(w, N, P)
     ctx.sync(); dt = time.perf_counter() - t0
     print(f"SC_TAIL_REM={os.environ.get('SC_TAIL_REM', 'default')}: {P} x {N}: {dt * 1e3:.1f} ms, stats {ctx.permgen_stats()}, state {w[:2]}", flush=True)
-if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE: clocks of the chain workgroup (thread 0) in computed blocks
-    st = ctx.debug_copy(5, 0, 8, np.uint64)
-    fp, hard = int(st[6]) & 0xffffffff, int(st[6]) >> 32
-    rounds, trounds, ntail = int(st[7]) & 0xfffff, (int(st[7]) >> 20) & 0xfffff, int(st[7]) >> 40
-    n_easy, n_hard = int(st[4]), int(st[5])
-    print(f"computed blocks: {n_hard} ({ntail} entered with <= one block of steps left), {64 * hard / max(n_hard, 1):.0f} clocks each, of which "
-          f"{64 * fp / max(n_hard, 1):.0f} in the fixed point; rounds: {trounds / max(ntail, 1):.1f} per tail block, "
-          f"{rounds / max(n_hard - ntail, 1):.1f} per other block")
+st = ctx.debug_copy(5, 0, 8, np.uint64)
+if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE
+    easy, hard = 64 * (int(st[6]) & 0xffffffff), 64 * (int(st[6]) >> 32)
+    print(f"chain clocks of the last job: lookup phases {easy / 1e6:.1f}M = {easy / max(int(st[4]), 1):.0f} per block, {easy / max(int(st[7]), 1):.0f} per pass "
+          f"({int(st[7])} passes); computed blocks {hard / 1e6:.1f}M = {hard / max(int(st[5]), 1):.0f} each")
+else:
+    print(f"last job: {int(st[4])} blocks by lookup, of which {int(st[6])} in fast passes ({int(st[7])} passes); {int(st[5])} computed")

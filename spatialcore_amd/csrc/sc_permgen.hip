@@ -769,11 +769,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
 {
     __shared__ BlockShared sh;
     __shared__ uint32_t shReady;
-    __shared__ PhiDesc dsc[PHI_UNIT];
+    __shared__ __align__(16) PhiDesc dsc[PHI_UNIT];
     __shared__ uint16_t nxt[PHI_UNIT + 2];  // first block >= i (relative to b0) the chain computes itself
     __shared__ unsigned long long shS, shB;
     __shared__ uint32_t shRem;
     __shared__ ulonglong2 tl[PHI_STAGE * PHI_STAGE_WORDS];  // [staged block][side][64 x 16 B]
+    __shared__ uint32_t tpre[PHI_STAGE * PHI_STAGE_WORDS];  // set bits in front of each 16-byte piece of its row
+    __shared__ int32_t candE[PHI_STAGE][64];                // fast run: exit offset (state - G) per candidate entry gap
+    __shared__ int32_t candBase[PHI_STAGE], candD[PHI_STAGE];
+    __shared__ unsigned long long passS[2];
+    __shared__ uint32_t passB[2], passRem[2];
+    __shared__ unsigned long long runS[PHI_UNIT];           // entry states of the blocks resolved by lookup in this run
     const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
     const uint32_t M = n - 1, top_mask = mask_of(M);
     uint64_t S = st[0];
@@ -784,7 +790,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     uint32_t parity = 0;
     int failed = 0;
     uint64_t endpos = 0;
-    uint32_t n_easy = 0, n_hard = 0;
+    uint32_t n_easy = 0, n_hard = 0, n_fast = 0, n_runs = 0;
+#ifdef PHI_PROFILE
+    unsigned long long pf_easy = 0, pf_hard = 0;
+#endif
     uint32_t rem = M - (uint32_t)(S % M);  // steps left in the current permutation, carried along from here
     uint64_t b_next = B0;
     // one launch chains several launch units (each prepared by its own launches; the host waited for all of them)
@@ -820,20 +829,144 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     static_assert(PHI_STAGE * PHI_STAGE_WORDS <= 3 * SCAN_THREADS, "three 16-byte chunks per thread");
     ulonglong2 treg[3];
     uint32_t un[SCAN_D];
+    // A SEGMENT is up to PHI_STAGE consecutive prepared blocks [rel, hcap) whose tables are staged in LDS; h is the
+    // next block the chain computes itself (h >= hcap; a long run of prepared blocks is several segments).
     uint32_t rel = 0, h = nxt[0];
-    uint32_t staged = h - rel < PHI_STAGE ? h - rel : PHI_STAGE;
-    PHI_STAGE_LOAD(rel, staged)
+    uint32_t hcap = h < rel + PHI_STAGE ? h : rel + PHI_STAGE;
+    PHI_STAGE_LOAD(rel, hcap - rel)
     if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
     for (;;) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (tau + SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) tl[tau + SCAN_THREADS * k] = treg[k];
+            if (SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) {   // a wavefront's 64 pieces are one (block, side) row
+                const uint32_t ones = (uint32_t)(__popcll(treg[k].x) + __popcll(treg[k].y));
+                const uint32_t upto = wave_inclusive_scan(ones);
+                if (tau + SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) {
+                    tl[tau + SCAN_THREADS * k] = treg[k];
+                    tpre[tau + SCAN_THREADS * k] = upto - ones;
+                }
+            }
+        // the run goes on behind this segment: its next segment's tables are on their way while this one is resolved
+        const bool more = hcap < h;
+        const uint32_t hcap2 = h < hcap + PHI_STAGE ? h : hcap + PHI_STAGE;
+        if (more) PHI_STAGE_LOAD(hcap, hcap2 - hcap)
         __syncthreads();
-        if (wave == 0) {  // run through the prepared blocks [rel, h)
-            uint32_t r = rel;
+        // ---- fast passes (r02) ----------------------------------------------------------------------------------
+        // A lookup by the lone wavefront 0 is ~1300 clocks of dependent instructions (0.6 us).  The entry gap of the
+        // following blocks is predictable to a few steps (it moves by the known difference of the guesses and shrinks by
+        // about the same fraction per block), so wavefront k resolves block cur + k for 64 CANDIDATE entry gaps around
+        // its prediction, one per lane, and wavefront 0 then only picks, block after block, the lane of the gap that
+        // really occurs (v_readlane, ~10 dependent instructions).  A gap outside a block's candidates ends the pass; the
+        // next pass starts there with the now known gap (its first block always hits).  Every picked value is the
+        // table's own: exactness is unaffected (and verified later like every prepared block).
+#ifdef PHI_PROFILE
+        const long long pf_t0 = clock64();
+#endif
+        uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+        const uint32_t hcap_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)hcap);
+        const uint32_t rel_u = cur;
+        bool stop = false;   // uniform
+        uint32_t pass_par = 0;
+        while (cur < hcap_u && !stop) {
+            const uint32_t left = hcap_u - cur;
+            const uint64_t S_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(S >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)S);
+            const PhiDesc d0 = dsc[cur];
+            const int64_t g0w = (int64_t)S_u - (int64_t)d0.G;
+            const bool neg0 = g0w < 0;
+            const uint64_t idx0 = (uint64_t)(neg0 ? -g0w : g0w);
+            if (idx0 > (neg0 ? d0.w_neg : d0.w_pos)) break;               // outside the prepared window: compute the block
+            if (idx0 > 64 * PHI_STAGE_WORDS) { stop = true; break; }      // beyond the staged bits: the lookup loop below
+            const int32_t g0 = (int32_t)g0w;
+            const uint32_t row0 = cur - rel_u;
+            const uint32_t T0 = idx0 ? phi_lookup_lds(tl + (row0 * 2 + (neg0 ? 1 : 0)) * 64, (uint32_t)idx0) : 0u;
+            // events shrink the gap by about the same FRACTION per block (their number is proportional to the gap)
+            const float keep = idx0 ? (float)T0 / (float)(uint32_t)idx0 : 1.f;
+            if (wave < left) {  // this wavefront's block: cur + wave
+                const uint32_t k = wave;
+                // predicted entry gap: c_{j+1} = keep c_j + (G_j + cnt_j - G_{j+1}), c_0 = g0, unrolled over the lanes
+                const float lk = __logf(keep > 1e-6f ? keep : 1e-6f);
+                float term = lane == 0 ? (float)g0 * __expf((float)k * lk) : 0.f;
+                if (lane < k) {
+                    const PhiDesc a = dsc[cur + lane], bb = dsc[cur + lane + 1];
+                    term += (float)(int32_t)(int64_t)(a.G + a.cnt - bb.G) * __expf((float)(k - 1 - lane) * lk);
+                }
+                // summed in 1/16 steps through the DPP prefix sum (a float butterfly would be six LDS-crossbar round trips)
+                const int32_t fixed = (int32_t)__builtin_rintf(term * 16.f);
+                const float c = (float)(int32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)fixed), 63) * 0.0625f;
+                const PhiDesc dk = dsc[cur + k];
+                const int32_t base = (k ? (int32_t)__builtin_rintf(c) : g0) - 32;
+                const int32_t g = base + (int32_t)lane;
+                const bool neg = g < 0;
+                const uint32_t idx = (uint32_t)(neg ? -g : g);
+                const bool ok = dk.prepared && idx <= (neg ? dk.w_neg : dk.w_pos) && idx <= 64 * PHI_STAGE_WORDS;
+                const uint32_t row = (row0 + k) * 2 + (neg ? 1u : 0u);
+                uint32_t T = 0;
+                if (ok && idx) {
+                    const uint32_t piece = (idx - 1u) >> 7, nbit = idx - 128u * piece;  // 1 .. 128 bits of that piece
+                    const ulonglong2 a = tl[row * 64 + piece];
+                    const uint32_t wd[4] = {(uint32_t)a.x, (uint32_t)(a.x >> 32), (uint32_t)a.y, (uint32_t)(a.y >> 32)};
+                    T = tpre[row * 64 + piece];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // 32-bit masks only (see xsl_rr32)
+                        const uint32_t lo = 32u * j;
+                        const uint32_t m = nbit >= lo + 32u ? 0xffffffffu : (nbit > lo ? ((1u << (nbit - lo)) - 1u) : 0u);
+                        T += (uint32_t)__popc(wd[j] & m);
+                    }
+                }
+                candE[k][lane] = ok ? (int32_t)dk.cnt + (neg ? -(int32_t)T : (int32_t)T) : (int32_t)0x80000000;
+                if (lane == 0) {
+                    candBase[k] = base;
+                    candD[k] = k + 1 < left ? (int32_t)(int64_t)(dk.G - dsc[cur + k + 1].G) : 0;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int32_t vE[PHI_STAGE];
+#pragma unroll
+                for (int k = 0; k < PHI_STAGE; ++k) vE[k] = candE[k][lane];
+                const int32_t vB = candBase[lane & (PHI_STAGE - 1)], vD = candD[lane & (PHI_STAGE - 1)];
+                int32_t g = g0, vg = 0, e_last = 0;
+                uint32_t K = 0;
+                bool live = true;
+#pragma unroll
+                for (int k = 0; k < PHI_STAGE; ++k) {
+                    if (live && (uint32_t)k < left) {   // uniform
+                        const uint32_t l = (uint32_t)(g - __builtin_amdgcn_readlane(vB, k));
+                        int32_t e = (int32_t)0x80000000;
+                        if (l < 64u) e = __builtin_amdgcn_readlane(vE[k], (int)l);
+                        if (e == (int32_t)0x80000000) live = false;
+                        else {
+                            vg = lane == (uint32_t)k ? g : vg;
+                            e_last = e;
+                            K = (uint32_t)k + 1;
+                            g = e + __builtin_amdgcn_readlane(vD, k);
+                        }
+                    }
+                }
+                // K >= 1: the first block's candidates are centred on its real gap, which lies inside its window
+                if (lane < K) runS[cur + lane] = dsc[cur + lane].G + (unsigned long long)(long long)vg;
+                if (lane == 0) {
+                    const PhiDesc dl = dsc[cur + K - 1];
+                    unsigned long long SS = dl.G + (unsigned long long)(long long)e_last;
+                    if (fault && n_easy == 0) SS += 1;  // testing: the verification must catch this
+                    passS[pass_par] = SS; passB[pass_par] = cur + K; passRem[pass_par] = dl.i_in - (uint32_t)e_last;
+                }
+                n_easy += K;
+                n_fast += K;
+                ++n_runs;
+            }
+            __syncthreads();
+            S = passS[pass_par];       // (the other buffer is rewritten only after the next pass's first barrier)
+            rem = passRem[pass_par];
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)passB[pass_par]);
+            pass_par ^= 1u;
+        }
+        if (wave == 0) {  // what the fast passes left of [rel, hcap): gaps beyond the staged bits (lookup in global memory)
+            uint32_t r = cur;
             uint64_t SS = S;
             uint32_t rr = rem;
-            while (r < h) {
+            while (stop && r < hcap) {
                 const PhiDesc dd = dsc[r];
                 const int64_t d = (int64_t)SS - (int64_t)dd.G;
                 const uint64_t idx = (uint64_t)(d < 0 ? -d : d);
@@ -841,12 +974,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                 const uint32_t side = d < 0 ? 1u : 0u;
                 uint32_t T = 0;
                 if (idx) {
-                    if (r - rel < staged && idx <= 64 * PHI_STAGE_WORDS)
+                    if (idx <= 64 * PHI_STAGE_WORDS)
                         T = phi_lookup_lds(tl + ((r - rel) * 2 + side) * 64, (uint32_t)idx);
                     else
                         T = phi_lookup(tbits + (((b0 + r) % PHI_RING) * 2 + side) * PHI_WORDS, (uint32_t)idx);
                 }
-                if (lane == 0) { sblk[b0 + r] = SS; hardmask[b0 + r] = 0; }
+                if (lane == 0) runS[r] = SS;   // flushed to sblk by the whole workgroup after the run
                 SS = dd.G + dd.cnt + (side ? -(int64_t)T : (int64_t)T);
                 if (fault && n_easy == 0) SS += 1;  // testing: the verification must catch this
                 rr = dd.i_in - (uint32_t)(SS - dd.G);  // no trajectory of the window leaves G's permutation
@@ -858,8 +991,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         __syncthreads();
         S = shS;
         rem = shRem;
-        const uint32_t x = (uint32_t)shB;  // first block not resolved by lookup: h, or earlier on a window miss
+        const uint32_t x = (uint32_t)shB;  // first block not resolved by lookup: hcap, or earlier on a window miss
+#ifdef PHI_PROFILE
+        const long long pf_t1 = clock64();
+        pf_easy += (unsigned long long)(pf_t1 - pf_t0);
+#endif
+        for (uint32_t i = rel + tau; i < x; i += SCAN_THREADS) { sblk[b0 + i] = runS[i]; hardmask[b0 + i] = 0; }
         if (x >= nb) { rel = nb; break; }
+        if (x == hcap && more) {  // the run's next segment (its tables are in treg already)
+            rel = hcap;
+            hcap = hcap2;
+            continue;
+        }
         uint32_t u[SCAN_D];
         const uint32_t hN = nxt[x + 1];
         if (x == h) {
@@ -868,9 +1011,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         } else {
             scan_load(raw, (b0 + x) * SCAN_BLOCK, tau, u);
         }
-        // on their way while block x is computed: the tables of the next run and the draws of the block after it
-        staged = hN - (x + 1) < PHI_STAGE ? hN - (x + 1) : PHI_STAGE;
-        PHI_STAGE_LOAD(x + 1, staged)
+        // on their way while block x is computed: the tables of the next segment and the draws of the block after it
+        const uint32_t ncap = hN < x + 1 + PHI_STAGE ? hN : x + 1 + PHI_STAGE;
+        PHI_STAGE_LOAD(x + 1, ncap - (x + 1))
         if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
         ScanRes r;
         uint32_t excl, total_cnt;
@@ -883,8 +1026,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         S += total_cnt;
         rem = rem_advance(rem, total_cnt, M);
         ++n_hard;
+#ifdef PHI_PROFILE
+        pf_hard += (unsigned long long)(clock64() - pf_t1);
+#endif
         rel = x + 1;
         h = hN;
+        hcap = ncap;
         if (S >= total_steps) break;
     }
     b_next = b0 + rel;
@@ -899,6 +1046,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         const uint64_t b = b_next;
         st[0] = S;
         st[1] = b;
+#ifdef PHI_PROFILE
+        st[6] += (pf_easy >> 6) | ((pf_hard >> 6) << 32);   // clocks / 64 of thread 0: lookup phases, computed blocks
+#else
+        st[6] += n_fast;  // ... of which by the fast passes
+#endif
+        st[7] += n_runs;
         st[4] += n_easy;  // wavefront 0 counted them
         st[5] += n_hard;
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
