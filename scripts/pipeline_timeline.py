@@ -22,21 +22,25 @@ def summarize(name):
     span=(ks[-1][1]-ks[0][0])/1e6
     gaps=sum(max(0,ks[i+1][0]-ks[i][1]) for i in range(len(ks)-1))/1e6
     print(f"{name:18s} n={len(ks):4d} busy {dur:7.1f} ms  span {span:7.1f} ms  gaps {gaps:7.1f} ms  first start {(ks[0][0]-base)/1e6:6.1f}  last end {(ks[-1][1]-base)/1e6:6.1f}")
-for n in ["k_chain","k_phi_events","k_phi_tbuild","k_block_exact","k_expand","k_apply_swaps","k_invert_perm","k_moran_perm32","k_moran_finalize32"]:
+names = sorted({r[2] for r in seg})
+def family(prefix):
+    return [n for n in names if n.startswith(prefix) or n.startswith("void " + prefix)]
+for n in ["k_chain", "k_phi_events", "k_phi_tbuild", "k_gate", "k_publish", "k_block_exact", "k_expand"] + family("k_apply_swaps") + family("k_moran_score") + family("k_moran_finalize"):
     summarize(n)
 # chain gap analysis: for each chain kernel, when did its prep (tbuild with same index) end?
 ch=[r for r in seg if r[2]=="k_chain"]; tb=[r for r in seg if r[2]=="k_phi_tbuild"]; evk=[r for r in seg if r[2]=="k_phi_events"]
-wait_prep=0; n=min(len(ch),len(tb))
+wait_prep=0; n=min(len(ch),len(tb)) if len(ch) == len(tb) else 0   # (r01 / early r02: one chain launch per unit)
 for i in range(n):
     if i>0:
         gap=ch[i][0]-ch[i-1][1]
         late=tb[i][1]-ch[i-1][1]
         if late>0: wait_prep+=min(gap,late)
-print(f"chain idle attributable to late preparation: {wait_prep/1e6:.1f} ms")
+if n: print(f"chain idle attributable to late preparation: {wait_prep/1e6:.1f} ms")
+print("chain launches: " + ", ".join(f"{(s_-base)/1e6:.1f}-{(e_-base)/1e6:.1f}" for s_, e_, _ in ch))
 print("events kernel avg %.0f us, tbuild avg %.0f us, chain avg %.0f us" % (sum(e-s for s,e,_ in evk)/len(evk)/1e3, sum(e-s for s,e,_ in tb)/len(tb)/1e3, sum(e-s for s,e,_ in ch)/len(ch)/1e3))
 print("--- kernels other than generator in the first 100 ms and the last 80 ms of the step")
 end=seg[-1][1]
 for s_,e_,n_ in seg:
-    if n_ in ("k_chain","k_phi_events","k_phi_tbuild"): continue
+    if n_ in ("k_chain","k_phi_events","k_phi_tbuild","k_gate","k_publish"): continue
     if (s_-base)/1e6 < 100 or (end-s_)/1e6 < 80:
         print(f"{(s_-base)/1e6:8.2f} -> {(e_-base)/1e6:8.2f}  {n_[:40]}")

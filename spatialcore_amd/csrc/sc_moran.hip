@@ -513,14 +513,21 @@ __global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ 
 //
 // z is rebuilt in registers from the raw value x: (double)x - mean is the very subtraction k_center performs, so
 // every product is bit-identical to the fp64-tile kernel's.  The gathered operand is a 128-byte row of
-//   * 64 uint16 genes when every loaded value is an integer count in [0, 65535]  (BITS = 16), else
-//   * 32 float32 genes when every value is a float32 (AnnData's usual dtype)      (BITS = 32),
-// instead of 16 fp64 genes: a quarter / half of the random-row bytes per gene.  The fp64 lag rows are the streamed,
-// coalesced operand and the INVERSE permutation supplies the gather index.
+//   * 128 uint8 genes when every loaded value is an integer count in [0, 255]     (BITS = 8; sums lag * x, the term
+//     mean * sum(lag) is taken off per statistic in the finalisation: 16 accumulators leave no registers for 16 means),
+//   * 64 uint16 genes when every loaded value is an integer count in [0, 65535]   (BITS = 16), else
+//   * 32 float32 genes when every value is a float32 (AnnData's usual dtype)       (BITS = 32),
+// instead of 16 fp64 genes: an eighth / quarter / half of the random-row bytes per gene.  The fp64 lag rows are the
+// streamed, coalesced operand and the INVERSE permutation supplies the gather index.
 //
-// Row layout (both widths): the 8 lanes q that share a row own genes {16 t + 2 q, 16 t + 2 q + 1 : t < TG} of the
-// group's TG 16-gene tiles (TG = 4 / 2), stored as the lane's 16 bytes [t][e]: a lane's lag operands are then TG
+// Row layout (all widths): the 8 lanes q that share a row own genes {16 t + 2 q, 16 t + 2 q + 1 : t < TG} of the
+// group's TG 16-gene tiles (TG = 8 / 4 / 2), stored as the lane's 16 bytes [t][e]: a lane's lag operands are then TG
 // 16-byte LDS reads that are contiguous across q (no bank conflicts), one per lag tile.
+//
+// What bounds the uint8 form (r02, 1M cells, 128 genes x 128 permutations, 3.56 ms on 248 CUs; diagnostic builds
+// -DSC_DIAG=n give wrong sums on purpose): half the LDS reads of lag 3.40 ms, no int -> fp64 conversions 3.50, neither
+// byte extraction nor conversion 3.44 -- neither LDS nor VALU issue; the gathered rows alone are 4.6 TB/s, with the
+// lag rows and indices ~5.7 TB/s memory-side: the random 128-byte gather at what the fabric sustains.
 // ------------------------------------------------------------------------------------------------
 
 // Narrow[group][cell][q][t][e] = X[TG * group + t][cell][2 q + e] as uint16 / float; *inexact |= a value does not fit
@@ -710,11 +717,21 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
+#if defined(SC_DIAG) && SC_DIAG == 1   /* diagnostic builds (wrong results): which resource bounds the kernel */
+                const double2 l = lr[(t & ~1) * 8];
+#else
                 const double2 l = lr[t * 8];
+#endif
                 double v0, v1;
                 if (BITS == 8) {
                     const uint32_t h = w[t >> 1] >> (16 * (t & 1));
+#if defined(SC_DIAG) && SC_DIAG == 2
+                    v0 = __hiloint2double(0x3ff00000, (int)(h & 0xffu)); v1 = __hiloint2double(0x3ff00000, (int)((h >> 8) & 0xffu));
+#elif defined(SC_DIAG) && SC_DIAG == 3
+                    v0 = __hiloint2double(0x3ff00000, (int)h); v1 = __hiloint2double(0x3ff00001, (int)h);
+#else
                     v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
+#endif
                 } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
                 else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
                 if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
