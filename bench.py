@@ -286,6 +286,17 @@ def main() -> None:
     swap_ms, _ = ctx.kernel_time(_lib.K_PERM_SWAP)
     knn_ms, _ = ctx.kernel_time(_lib.K_KNN)
     fallbacks = int(comm.max_over_ranks([float(pg[2])])[0])
+    # The same kernel with the chip to itself (after the timed region, rank 0, single batch): the first 128 permutations
+    # of the resident table scored again.  Inside the pipeline it runs on the CUs it leaves to the generator's side
+    # and beside the generator's traffic; this is the kernel's own rate.  Reported as roofline.alone, never as `value`.
+    alone = None
+    if rank == 0 and len(batches) == 1 and not rehearse and P >= 128:
+        ctx.reset_timers()
+        for _ in range(3):
+            ctx.moran(128, return_sims=False)
+        a_ms, a_cnt = ctx.kernel_time(_lib.K_MORAN_PERM)
+        if a_cnt:
+            alone = (a_ms / a_cnt, 128)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -357,7 +368,13 @@ def main() -> None:
                          "effective_basis": "SURVEY 8(d) streaming model, 16 B per (permutation, gene, cell) + 4 B per "
                                             "(permutation, cell); may exceed the peak, the kernel moves fewer bytes",
                          "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and perm_launches else None,
-                         "traffic_source": traffic_note},
+                         "traffic_source": traffic_note,
+                         "alone": None if alone is None else {
+                             "launch_ms": alone[0], "permutations": alone[1],
+                             "achieved": (groups * alone[1] * n * 132.0 + n * 8.0 * G_pad) / (alone[0] * 1e-3) / 1e9,
+                             "frac": (groups * alone[1] * n * 132.0 + n * 8.0 * G_pad) / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "the same kernel on the whole chip, no generator beside it (128 permutations of the "
+                                     "resident table, after the timed region)"}},
             "breakdown_ms_per_step": {"perm_scan_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
                                       "moran_perm_kernel": perm_ms / args.steps,
                                       "lag_kernel": lag_ms / args.steps, "knn_kernel": knn_ms / args.steps},
