@@ -181,6 +181,8 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline + oracle verification leg")
     ap.add_argument("--no-public-api", action="store_true")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip roofline.alone (counter passes: its launches would be averaged into the per-launch traffic)")
     ap.add_argument("--source-bits", type=int, default=8, choices=(8, 16, 32, 64),
                     help="narrowest exact copy of the expression values the permutation kernel may gather "
                          "(8 / 16: uint8 / uint16 for count data, 32: float32 raw values, 64: the general fp64 kernel)")
@@ -290,7 +292,7 @@ def main() -> None:
     # of the resident table scored again.  Inside the pipeline it runs on the CUs it leaves to the generator's side
     # and beside the generator's traffic; this is the kernel's own rate.  Reported as roofline.alone, never as `value`.
     alone = None
-    if rank == 0 and len(batches) == 1 and not rehearse and P >= 128:
+    if rank == 0 and len(batches) == 1 and not rehearse and P >= 128 and not args.no_alone:
         ctx.reset_timers()
         for _ in range(3):
             ctx.moran(128, return_sims=False)

@@ -2,8 +2,8 @@
 
 Usage (on the GPU box, after two separate counter passes of the same command):
 
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api --no-alone
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api --no-alone
     python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write k_moran_score gpurun_out/pmc_out
 
 Writes <out>/<kernel>_pmc_traffic.json (read by bench.py for roofline.traffic) and
@@ -78,7 +78,7 @@ def main() -> None:
         "fetch_doubled": double_fetch,
         "hbm_bytes_per_launch": hbm,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of "
-                  "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`, aggregated by scripts/pmc_traffic.py; "
+                  "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api --no-alone`, aggregated by scripts/pmc_traffic.py; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B-per-lane "
                   "reads; every load of this kernel is 16 B per lane); the counters are L2 memory-side requests, "
                   "Infinity-Cache hits included",
