@@ -68,6 +68,9 @@ struct sc_ctx {
     hipStream_t stream_px = nullptr;     // ... and verifies + expands a finished chunk here, beside the next chunk's chain
     hipEvent_t pg_ev[34] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
+    bool pg_streams_serial = false;   // a wait on a hand-over word gave up once: the streams of this process do not run
+                                      // concurrently (profiler that serialises kernels, shared hardware queues) --
+                                      // later jobs take the sequential scan at once instead of waiting 10 s again
     int pg_ahead = 1;                 // launch units the preparation runs ahead of the chain (callers that share the chip raise it)
     int64_t pg_jobs_parallel = 0, pg_jobs_sequential = 0, pg_fallbacks = 0;  // generator jobs by scan form
     int64_t pg_blocks_prepared = 0, pg_blocks_chain = 0;  // block-parallel jobs: blocks resolved by table lookup / by the chain workgroup

@@ -1248,7 +1248,7 @@ static double expected_draws_per_perm(int64_t n)
     return e;
 }
 
-bool permgen_is_block_parallel(const sc_ctx *c, int64_t n) { return c->pg_mode != 1 && n >= PHI_MIN_N; }
+bool permgen_is_block_parallel(const sc_ctx *c, int64_t n) { return c->pg_mode != 1 && !c->pg_streams_serial && n >= PHI_MIN_N; }
 
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s)
 {
@@ -1456,6 +1456,7 @@ int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
     if (job->phi) { c->pg_blocks_prepared += (int64_t)st[4]; c->pg_blocks_chain += (int64_t)st[5]; }
     if (job->phi && st[2] != 0) {  // verification of the block-parallel scan failed: the caller reruns sequentially
         c->pg_fallbacks += 1;
+        if (st[2] & 24ull) c->pg_streams_serial = true;  // a hand-over wait gave up (flags 8 / 16)
         sc_set_error("sc_perm_generate: block-parallel scan failed its verification (flags %llu)", st[2]);
         return SC_PERMGEN_RETRY;
     }

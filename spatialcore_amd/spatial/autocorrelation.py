@@ -160,14 +160,19 @@ def build_spatial_weights(adata, n_neighbors: int = 6, spatial_key: str = "spati
 # =============================================================================================
 
 
-def _squidpy_neighbors(ctx, adata, coords, n_neighbors: int, spatial_key: str):
-    """What ``sq.gr.spatial_neighbors(adata, n_neighs=k, coord_type='generic')`` leaves behind
-    (AC:565-570) [upstream squidpy]: binary float64 connectivities + euclidean distances in
-    ``adata.obsp`` and a ``uns['spatial_neighbors']`` record; the row-normalised graph (squidpy's
-    ``transformation=True``) becomes the active device graph."""
-    n = coords.shape[0]
+def _knn_device_graph(ctx, coords, n_neighbors: int):
+    """Device half of squidpy's neighbour step: exact kNN, and the row-normalised graph (squidpy's
+    ``transformation=True``) as the active device graph.  Returns the neighbour indices and squared distances."""
     idx, rd = ctx.knn(coords, n_neighbors, return_distance=True)
     ctx.graph_from_knn(1.0 / n_neighbors)
+    return idx, rd
+
+
+def _record_squidpy_neighbors(adata, idx, rd, n_neighbors: int) -> None:
+    """Host half: what ``sq.gr.spatial_neighbors(adata, n_neighs=k, coord_type='generic')`` leaves behind
+    (AC:565-570) [upstream squidpy]: binary float64 connectivities + euclidean distances in ``adata.obsp`` and a
+    ``uns['spatial_neighbors']`` record."""
+    n = idx.shape[0]
     indptr = np.arange(0, n * n_neighbors + 1, n_neighbors, dtype=np.int64)
     conn = csr_matrix((np.ones(idx.size, dtype=np.float64), idx.reshape(-1), indptr), shape=(n, n))
     dist = csr_matrix((np.sqrt(rd).reshape(-1), idx.reshape(-1), indptr.copy()), shape=(n, n))
@@ -178,6 +183,36 @@ def _squidpy_neighbors(ctx, adata, coords, n_neighbors: int, spatial_key: str):
         "distances_key": "spatial_distances",
         "params": {"n_neighbors": n_neighbors, "coord_type": "generic", "radius": None, "transform": None},
     }
+
+
+def _squidpy_neighbors(ctx, adata, coords, n_neighbors: int, spatial_key: str):
+    idx, rd = _knn_device_graph(ctx, coords, n_neighbors)
+    _record_squidpy_neighbors(adata, idx, rd, n_neighbors)
+
+
+def _beside(device_call, host_call):
+    """Run one blocking library call (ctypes releases the GIL) beside host-side assembly that does not touch the
+    device context; the host work always completes, then either side's exception propagates (the device call's first:
+    it is the later step of the sequential order)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = device_call()
+        except BaseException as exc:   # re-raised in the caller's thread
+            box["error"] = exc
+
+    worker = threading.Thread(target=run, name="spatialcore-upload")
+    worker.start()
+    try:
+        host_call()
+    finally:
+        worker.join()
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
 
 
 def _upload_existing_graph(ctx, g) -> None:
@@ -298,6 +333,7 @@ def morans_i(
                                "This indicates an internal error in squidpy or data corruption.")
 
     ctx = _lib.default_context(device)
+    knn_found = None
     if use_existing_graph and "spatial_connectivities" in adata.obsp:
         logger.info("Using existing spatial connectivity graph (use_existing_graph=True)")
         _upload_existing_graph(ctx, adata.obsp["spatial_connectivities"])
@@ -310,7 +346,7 @@ def morans_i(
                                                      "transform": None}}
     else:
         logger.debug(f"Building spatial neighbors graph (k={n_neighbors})")
-        _squidpy_neighbors(ctx, adata, coords, n_neighbors, spatial_key)
+        knn_found = _knn_device_graph(ctx, coords, n_neighbors)
 
     cols, where = _unique_columns(adata, gene_names)
     # Genes are scored in batches that fit the device (four tile sets of n_cells x 8 bytes per gene, ~1/2 of the HBM
@@ -324,11 +360,19 @@ def morans_i(
     for b0 in range(0, cols.size, per_batch):
         part = cols[b0:b0 + per_batch]
         if sparse.issparse(X) and cols.size > per_batch:
-            ctx.set_expression(X[:, part], np.arange(part.size, dtype=np.int32))
+            upload = lambda: ctx.set_expression(X[:, part], np.arange(part.size, dtype=np.int32))
         else:
-            ctx.set_expression(X, part)
+            upload = lambda: ctx.set_expression(X, part)
+        if knn_found is not None:
+            # the first batch's upload (PCIe) runs beside the host-side assembly of squidpy's obsp / uns side effects
+            _beside(upload, lambda: _record_squidpy_neighbors(adata, knn_found[0], knn_found[1], n_neighbors))
+            knn_found = None
+        else:
+            upload()
         res = _moran_resident(ctx, n_cells, n_permutations, seed, reuse_table=b0 > 0)
         score[b0:b0 + per_batch], p_all[b0:b0 + per_batch] = res["I"], res["p_value"]
+    if knn_found is not None:   # (no gene batch ran)
+        _record_squidpy_neighbors(adata, knn_found[0], knn_found[1], n_neighbors)
     var_norm, expected_I = res["var_norm"], res["expected_I"]
 
     results = []
