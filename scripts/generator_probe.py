@@ -11,7 +11,7 @@ for rep in range(3):
     ctx.sync(); t0 = time.perf_counter()
     ctx.generate_permutations(w, N, P)
     ctx.sync(); dt = time.perf_counter() - t0
-    print(f"SC_TAIL_REM={os.environ.get('SC_TAIL_REM', 'default')}: {P} x {N}: {dt * 1e3:.1f} ms, stats {ctx.permgen_stats()}, state {w[:2]}", flush=True)
+    print(f"{P} x {N}: {dt * 1e3:.1f} ms, stats {ctx.permgen_stats()}, state {w[:2]}", flush=True)
 st = ctx.debug_copy(5, 0, 8, np.uint64)
 if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE
     easy, hard = 64 * (int(st[6]) & 0xffffffff), 64 * (int(st[6]) >> 32)
