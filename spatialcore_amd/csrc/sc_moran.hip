@@ -1239,7 +1239,20 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
                                c->stream, c->inv.as<int32_t>() + p0 * c->p_stride, c->perm.as<int32_t>() + p0 * c->p_stride,
                                c->e_n, c->p_stride, rows);
         }
-        return moran_perm_range(c, p0, p1, bits, false);
+        // The last chunk is scored after the generator has finished (its own swaps are the generator's last launches):
+        // it takes the CUs the earlier launches left to the generator; the one before it runs beside the generator's
+        // short last chunk only.  SC_SCORE_LEAVE_TAIL="a,b" (development): CUs left by the second-to-last / last
+        // chunk's launch; measured at bench size (ms per step): 64,64 -> 211.5, 64,8 -> 209.9, 32,8 -> 207.1, 8,8 -> 207.9.
+        const int keep = c->score_leave_cus;
+        if (keep > 8) {
+            int tail_prev = keep < 32 ? keep : 32, tail_last = 8;
+            if (const char *v = getenv("SC_SCORE_LEAVE_TAIL")) sscanf(v, "%d,%d", &tail_prev, &tail_last);
+            if (p1 == n_perm) c->score_leave_cus = tail_last;
+            else if (PIPE_LAST > 0 && n_perm - p1 <= PIPE_LAST) c->score_leave_cus = tail_prev;
+        }
+        const int rc = moran_perm_range(c, p0, p1, bits, false);
+        c->score_leave_cus = keep;
+        return rc;
     };
     SC_TRY(sc_perm_pipeline(c, state6, n, n_perm, inverse_only ? 1 : 2, prepare, score));
     if (need_forward) c->perm_forward_valid = true;
