@@ -103,3 +103,49 @@ def test_rccl_communicator_world_of_one():
         comm.close()
     with pytest.raises(ValueError):
         RcclComm(ctx, b"short", 1, 0)
+
+
+_SERIAL_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from spatialcore_amd import _lib
+n, P = 1_000_000, 150                     # block-parallel generator first; a 128-permutation chunk is 22 launch units
+ctx = _lib.Context(0)
+rng = np.random.default_rng(5)
+coords = rng.uniform(0, 10000, (n, 2))
+X = rng.poisson(1.0, (n, 20)).astype(np.float32)
+ctx.knn(coords, 6, fetch=False); ctx.graph_from_knn(1.0 / 6)
+ctx.set_expression(X, np.arange(20))
+walls, outs = [], []
+for rep in range(2):
+    w = _lib.rng_state_words(np.random.default_rng(9))
+    t0 = time.perf_counter()
+    outs.append(ctx.moran_seeded(w, P))
+    walls.append(time.perf_counter() - t0)
+    wh = _lib.rng_state_words(np.random.default_rng(9))
+    _lib.perm_numpy_host(wh, n, P)
+    np.testing.assert_array_equal(w, wh)                     # generator state after P numpy permutations
+par, seq, fallbacks = ctx.permgen_stats()[:3]
+for key in ("I", "sims", "count_ge"):
+    np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
+print("STATS", par, seq, fallbacks, walls[0], walls[1], flush=True)
+"""
+
+
+def test_generator_without_concurrent_streams_falls_back_once(tmp_path):
+    """The block-parallel generator orders its launches through words in device memory, which needs its streams to run
+    concurrently.  With two hardware queues for a dozen streams they cannot: the first job must notice (its waits give
+    up after 10 s), rerun with the sequential scan and return the numpy-exact result; the context must then stay with
+    the sequential form (no second wait)."""
+    script = tmp_path / "serial_worker.py"
+    script.write_text(_SERIAL_WORKER.format(root=ROOT))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2")
+    run = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    stats = [ln for ln in run.stdout.splitlines() if ln.startswith("STATS")][-1].split()
+    par, seq, fallbacks, first, second = int(stats[1]), int(stats[2]), int(stats[3]), float(stats[4]), float(stats[5])
+    if fallbacks == 0:
+        pytest.skip("the runtime ran the streams concurrently on two hardware queues: nothing to fall back from")
+    assert (par, seq, fallbacks) == (0, 2, 1), stats
+    assert first > 9.0 and second < 5.0, stats     # one 10-s give-up, then the sequential form at once
