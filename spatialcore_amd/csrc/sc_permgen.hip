@@ -731,13 +731,14 @@ __device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_
 #define PHI_FLAG_SLOTS 16
 #define PHI_WAIT_TICKS 1000000000ll   // 10 s of the 100 MHz wall clock (a chunk of 128 permutations of 3 x 10^7 cells takes ~1 s)
 
-__device__ __forceinline__ bool phi_wait_at_least(const uint32_t *flag, uint32_t want, const unsigned long long *st)
+// 0: the word arrived; 1: gave up waiting (the caller raises its flag); 2: abandoned, a failure flag is up already
+__device__ __forceinline__ int phi_wait_at_least(const uint32_t *flag, uint32_t want, const unsigned long long *st)
 {
     const long long t0 = wall_clock64();
     for (uint32_t spins = 0;; ++spins) {
-        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-        if (__hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return false;
-        if (wall_clock64() - t0 > PHI_WAIT_TICKS || spins > (1u << 28)) return false;
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return 0;
+        if (__hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return 2;
+        if (wall_clock64() - t0 > PHI_WAIT_TICKS || spins > (1u << 28)) return 1;
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -749,7 +750,7 @@ __global__ void k_publish(uint32_t *flags, uint32_t slot, uint32_t value)
 
 __global__ void k_gate(const uint32_t *flags, uint32_t chain_units_needed, unsigned long long *st)
 {
-    if (threadIdx.x == 0 && !phi_wait_at_least(flags, chain_units_needed, st)) atomicOr(st + 2, 16ull);
+    if (threadIdx.x == 0 && phi_wait_at_least(flags, chain_units_needed, st) == 1) atomicOr(st + 2, 16ull);
 }
 
 // Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
@@ -803,9 +804,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     const uint64_t b1 = b0 + PHI_UNIT < B1 ? b0 + PHI_UNIT : B1;
     const uint32_t nb = (uint32_t)(b1 - b0);
     __syncthreads();  // the previous unit's readers of dsc / nxt / tl are done
-    if (tau == 0) shReady = phi_wait_at_least(flags + 1 + unit % PHI_FLAG_SLOTS, unit + 1, st) ? 1u : 0u;
+    if (tau == 0) shReady = (uint32_t)phi_wait_at_least(flags + 1 + unit % PHI_FLAG_SLOTS, unit + 1, st);
     __syncthreads();
-    if (!shReady) { gave_up = 1; break; }
+    if (shReady) { gave_up = (int)shReady; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the unit's descriptors and tables, written by other kernels
     if (tau < nb) dsc[tau] = desc[(b0 + tau) % PHI_RING];
     __syncthreads();
@@ -1057,10 +1058,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
         unsigned long long f = 0;  // (k_block_exact of the previous chunk may be raising its own flag right now)
         if (failed) f |= 1ull;
-        if (gave_up) f |= 8ull;  // a unit's preparation did not arrive
+        if (gave_up == 1) f |= 8ull;  // a unit's preparation did not arrive in time
         if (S < S_need && S < total_steps) f |= 2ull;  // the blocks granted to this chunk did not complete it
         if (f) atomicOr(st + 2, f);
-        if (f || S >= total_steps)  // nothing more will come from the chain: release every gate
+        if (f || gave_up || S >= total_steps)  // nothing more will come from the chain: release every gate
             __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
