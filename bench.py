@@ -164,6 +164,53 @@ def public_api_rate(coords, X, k: int, P: int, seed: int, device: int):
     return X.shape[1] / walls[1], walls, ad.uns["morans_i"]
 
 
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N child processes of this same command with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (and a rendezvous file in a fresh private directory)
+    set, pass their output through (rank 0 prints the one JSON line), wait for all of them, and return non-zero if
+    any failed.  The launcher never touches the GPU, so nothing is exec'ed or forked from a process with HIP state."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdv_dir = tempfile.mkdtemp(prefix="sc_bench_rdv_")      # 0700, this launch only
+    procs = []
+    try:
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       SC_RENDEZVOUS_FILE=os.path.join(rdv_dir, "rccl_id"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        codes = [None] * n_ranks
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed:                      # a dead rank would leave the others waiting in a collective
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()       # exactly the processes started above
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[r] = p.wait()
+                print(f"bench.py launcher: rank(s) {failed} failed (exit codes {[codes[r] for r in failed]})",
+                      file=sys.stderr, flush=True)
+                return 1
+            time.sleep(0.05)
+        return 0
+    finally:
+        shutil.rmtree(rdv_dir, ignore_errors=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,12 +238,15 @@ def main() -> None:
                          "devices); exercises the N > 1 code path on a 1-GPU box; never a measurement")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked directly (`python bench.py --gpus N`): this process becomes the launcher of N ranks.  It has made
+        # no GPU call and has not even loaded the HIP library; the ranks are fresh child processes.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
-                         "(python -m torch.distributed.run --nproc-per-node N ...)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     rehearse = args.rehearse_on_one_gpu
     if rehearse:
         local_rank = 0
@@ -216,6 +266,7 @@ def main() -> None:
 
     ctx = _lib.Context(local_rank)
     comm = parallel.connect(ctx, transport="file" if rehearse else None)
+    comm_ranks = comm.info()[0]     # what RCCL reports (ncclCommCount) when the transport is RCCL
     ctx.set_moran_source_bits(args.source_bits)
 
     # ---- synthetic inputs; resident in HBM before the timed region (weak mode: the rank's whole matrix) ----
@@ -384,6 +435,7 @@ def main() -> None:
                               "verification_fallbacks_max_over_ranks": fallbacks,
                               "blocks_prepared": pg[3], "blocks_chain": pg[4]},
             "device_mem_bytes_rank0": mem_peak,
+            "nccl_ranks": comm_ranks,
         }
         if fallbacks:
             line["warning"] = "the block-parallel generator fell back to the sequential scan inside the timed region"

@@ -265,13 +265,18 @@ int sc_enrichment_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t 
  * use.  Rendezvous: one rank calls sc_comm_unique_id and passes the 128 bytes to the others by any side channel
  * (spatialcore_amd/parallel.py: a file keyed by the launcher's environment); all ranks call sc_comm_create.
  * sc_allgather: host arrays; every rank contributes `count` doubles, out holds world * count, in rank order.
- * sc_allreduce_max: in-place element-wise maximum over ranks (bench: slowest rank's clock; doubles as a barrier). */
+ * sc_allreduce_max: in-place element-wise maximum over ranks (bench: slowest rank's clock; doubles as a barrier).
+ * sc_allreduce_sum_i64: in-place element-wise integer sum over ranks (permutation sharding, SURVEY 8(e) "alternative":
+ *   ranks score disjoint permutation ranges and add their exceedance counts -- integers, hence exact and order-free).
+ * sc_comm_info: what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice). */
 typedef struct sc_comm sc_comm;
 int sc_comm_unique_id(uint8_t *id_out_128);
 int sc_comm_create(sc_ctx *ctx, const uint8_t *id_128, int world, int rank, sc_comm **out);
 int sc_comm_destroy(sc_comm *comm);
 int sc_allgather(sc_comm *comm, const double *local, int64_t count, double *out);
 int sc_allreduce_max(sc_comm *comm, double *values, int64_t count);
+int sc_allreduce_sum_i64(sc_comm *comm, int64_t *values, int64_t count);
+int sc_comm_info(sc_comm *comm, int *world_out, int *rank_out, int *device_out);
 
 #ifdef __cplusplus
 }

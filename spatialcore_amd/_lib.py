@@ -73,6 +73,8 @@ SYMBOLS = {
     "sc_comm_destroy": [_P],
     "sc_allgather": [_P, _P, c_int64, _P],
     "sc_allreduce_max": [_P, _P, c_int64],
+    "sc_allreduce_sum_i64": [_P, _P, c_int64],
+    "sc_comm_info": [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
 }
 
 _lib = None
@@ -532,6 +534,21 @@ class RcclComm:
         v = np.array(values, dtype=np.float64, ndmin=1)
         _check(self._lib.sc_allreduce_max(self._h, _ptr(v), v.size))
         return v
+
+    def sum_over_ranks_i64(self, values) -> np.ndarray:
+        """Element-wise integer sum over ranks (exact; used to merge exceedance counts of permutation shards)."""
+        v = np.array(values, dtype=np.int64, ndmin=1)
+        shape = v.shape
+        v = np.ascontiguousarray(v.reshape(-1))
+        if v.size:
+            _check(self._lib.sc_allreduce_sum_i64(self._h, _ptr(v), v.size))
+        return v.reshape(shape)
+
+    def info(self) -> Tuple[int, int, int]:
+        """(ranks, this rank, device) as RCCL itself reports them for this communicator."""
+        w, r, d = c_int(0), c_int(0), c_int(0)
+        _check(self._lib.sc_comm_info(self._h, byref(w), byref(r), byref(d)))
+        return w.value, r.value, d.value
 
     def barrier(self) -> None:
         self.max_over_ranks([0.0])

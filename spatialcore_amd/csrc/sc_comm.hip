@@ -23,7 +23,10 @@ typedef int (*fn_comm_destroy)(RcclComm);
 typedef const char *(*fn_error_string)(int);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, RcclComm, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t);
+typedef int (*fn_comm_int)(const RcclComm, int *);
 const int kRcclFloat64 = 8;  // ncclFloat64
+const int kRcclInt64 = 4;    // ncclInt64
+const int kRcclSum = 0;      // ncclSum
 const int kRcclMax = 2;      // ncclMax
 
 struct Rccl {
@@ -34,6 +37,7 @@ struct Rccl {
     fn_error_string error_string = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
+    fn_comm_int comm_count = nullptr, comm_user_rank = nullptr, comm_device = nullptr;
 } g_rccl;
 
 int rccl_load()
@@ -52,7 +56,10 @@ int rccl_load()
     r.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
     r.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
     r.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.error_string || !r.all_gather || !r.all_reduce) {
+    r.comm_count = (fn_comm_int)dlsym(h, "ncclCommCount");
+    r.comm_user_rank = (fn_comm_int)dlsym(h, "ncclCommUserRank");
+    r.comm_device = (fn_comm_int)dlsym(h, "ncclCommCuDevice");
+    if (!r.comm_count || !r.comm_user_rank || !r.comm_device || !r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.error_string || !r.all_gather || !r.all_reduce) {
         dlclose(h);
         sc_set_error("librccl.so lacks an expected nccl* entry point");
         return SC_ERR_STATE;
@@ -157,5 +164,32 @@ extern "C" int sc_allreduce_max(sc_comm *m, double *values, int64_t count)
     SC_RCCL(g_rccl.all_reduce(m->send.p, m->send.p, (size_t)count, kRcclFloat64, kRcclMax, m->comm, c->stream));
     SC_HIP(hipMemcpyAsync(values, m->send.p, bytes, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// values[k] <- sum over ranks (int64, in place, host array): exceedance counts of permutation-sharded runs.
+extern "C" int sc_allreduce_sum_i64(sc_comm *m, int64_t *values, int64_t count)
+{
+    SC_REQUIRE(m && values, SC_ERR_INVALID, "sc_allreduce_sum_i64: null pointer");
+    SC_REQUIRE(count >= 1 && count <= ((int64_t)1 << 28), SC_ERR_INVALID, "sc_allreduce_sum_i64: count out of range");
+    sc_ctx *c = m->ctx;
+    SC_HIP(hipSetDevice(c->device));
+    const size_t bytes = sizeof(int64_t) * (size_t)count;
+    SC_TRY(m->send.ensure(bytes, &m->mem));
+    SC_HIP(hipMemcpyAsync(m->send.p, values, bytes, hipMemcpyHostToDevice, c->stream));
+    SC_RCCL(g_rccl.all_reduce(m->send.p, m->send.p, (size_t)count, kRcclInt64, kRcclSum, m->comm, c->stream));
+    SC_HIP(hipMemcpyAsync(values, m->send.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    return SC_OK;
+}
+
+// what RCCL reports for the communicator: number of ranks, this rank, the device it is bound to
+extern "C" int sc_comm_info(sc_comm *m, int *world_out, int *rank_out, int *device_out)
+{
+    SC_REQUIRE(m && m->comm, SC_ERR_INVALID, "sc_comm_info: null communicator");
+    int v = 0;
+    if (world_out) { SC_RCCL(g_rccl.comm_count(m->comm, &v)); *world_out = v; }
+    if (rank_out) { SC_RCCL(g_rccl.comm_user_rank(m->comm, &v)); *rank_out = v; }
+    if (device_out) { SC_RCCL(g_rccl.comm_device(m->comm, &v)); *device_out = v; }
     return SC_OK;
 }

@@ -66,6 +66,31 @@ def rendezvous_file(seq: int = 0) -> str:
     return f"{base}.{seq}"
 
 
+def _launch_nonce() -> bytes:
+    """16 bytes that every rank of ONE launch computes alike and no other launch does (launcher pid + start time +
+    port + uid): rank 0 prefixes the RCCL id with it, the others ignore files that carry another one -- a file left
+    behind by a crashed launch, or put at a predictable path by someone else, is never taken for this launch's id."""
+    import hashlib
+
+    return hashlib.sha256(("sc-rdv-v1:" + _launcher_identity()).encode()).digest()[:16]
+
+
+def _await_id(path: str, nonce: bytes, id_bytes: int, timeout_s: float) -> bytes:
+    """Poll `path` until it holds `nonce` + an id of `id_bytes` bytes; stale or foreign files are skipped."""
+    deadline = time.monotonic() + timeout_s
+    while True:
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+            if len(raw) == len(nonce) + id_bytes and raw[:len(nonce)] == nonce:
+                return raw[len(nonce):]
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rendezvous file {path} with this launch's nonce did not appear within {timeout_s:.0f}s")
+        time.sleep(0.005)
+
+
 def _publish(path: str, payload: bytes) -> None:
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "wb") as f:
@@ -114,6 +139,16 @@ class FileComm:
 
     def max_over_ranks(self, values) -> np.ndarray:
         return self.all_gather(np.array(values, dtype=np.float64, ndmin=1)).max(axis=0)
+
+    def sum_over_ranks_i64(self, values) -> np.ndarray:
+        v = np.array(values, dtype=np.int64, ndmin=1)
+        # the blocks travel as float64 bytes: split into 32-bit halves so that every integer arrives exactly
+        halves = np.stack([v >> 32, v & 0xFFFFFFFF]).astype(np.float64)
+        got = self.all_gather(halves).astype(np.int64)
+        return ((got[:, 0] << 32) + got[:, 1]).sum(axis=0)
+
+    def info(self) -> Tuple[int, int, int]:
+        return self.world, self.rank, -1
 
     def barrier(self) -> None:
         self.all_gather(np.zeros(1))
@@ -165,6 +200,12 @@ class _SoloComm:
     def max_over_ranks(self, values):
         return np.array(values, dtype=np.float64, ndmin=1)
 
+    def sum_over_ranks_i64(self, values):
+        return np.array(values, dtype=np.int64, ndmin=1)
+
+    def info(self):
+        return 1, 0, -1
+
     def barrier(self):
         pass
 
@@ -195,11 +236,12 @@ def connect(ctx=None, transport: Optional[str] = None, timeout_s: Optional[float
         raise ValueError("the RCCL transport needs the rank's GPU context")
     from spatialcore_amd import _lib
 
+    nonce = _launch_nonce()
     if rank == 0:
         uid = _lib.RcclComm.unique_id()
-        _publish(path, uid)
+        _publish(path, nonce + uid)
     else:
-        uid = _await_file(path, timeout_s)
+        uid = _await_id(path, nonce, _lib.RcclComm.ID_BYTES, timeout_s)
     comm = _lib.RcclComm(ctx, uid, world, rank)     # returns once every rank has joined, i.e. has read the id
     if rank == 0:
         try:

@@ -229,6 +229,9 @@ c = connect(None, transport="file")
 assert c.max_over_ranks([float(rank), 5.0 - rank]).tolist() == [1.0, 5.0]
 got = c.all_gather(np.full((2, 3), float(rank)))
 assert got.shape == (2, 2, 3) and (got[0] == 0).all() and (got[1] == 1).all()
+big = np.array([[2**40 + 3 + rank, 7], [rank, 2**62 // 4]], dtype=np.int64)     # integers beyond float64's 2^53 survive
+np.testing.assert_array_equal(c.sum_over_ranks_i64(big), np.array([[2**41 + 7, 14], [1, 2**61]], dtype=np.int64))
+assert c.info()[:2] == (2, rank)
 c.barrier(); c.close()
 """
 
@@ -276,3 +279,54 @@ def test_rendezvous_name_is_shared_by_siblings_and_overridable(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     solo = parallel.connect()
     assert solo.world == 1 and solo.all_gather(np.ones(3)).shape == (1, 3)
+
+
+def test_rendezvous_ignores_stale_and_foreign_files(tmp_path, monkeypatch):
+    """A file left at the rendezvous path by an earlier (crashed) launch, or put there by someone else, carries
+    another launch nonce (or none): a reader keeps polling until THIS launch's rank 0 has published."""
+    import threading
+    import time
+
+    from spatialcore_amd import parallel
+
+    monkeypatch.setenv("MASTER_PORT", "29998")
+    path = str(tmp_path / "rdv.0")
+    nonce = parallel._launch_nonce()
+    assert len(nonce) == 16 and nonce == parallel._launch_nonce()
+    monkeypatch.setenv("MASTER_PORT", "29997")
+    assert parallel._launch_nonce() != nonce                    # another launch, another nonce
+    monkeypatch.setenv("MASTER_PORT", "29998")
+    with open(path, "wb") as f:
+        f.write(b"\x01" * 128)                                  # pre-nonce format / foreign file
+    with pytest.raises(TimeoutError):
+        parallel._await_id(path, nonce, 128, 0.2)
+    with open(path, "wb") as f:
+        f.write(b"\x02" * 16 + b"\x03" * 128)                   # right size, someone else's nonce
+    with pytest.raises(TimeoutError):
+        parallel._await_id(path, nonce, 128, 0.2)
+
+    def late_rank0():
+        time.sleep(0.3)
+        parallel._publish(path, nonce + b"\x07" * 128)
+
+    t = threading.Thread(target=late_rank0)
+    t.start()
+    assert parallel._await_id(path, nonce, 128, 10.0) == b"\x07" * 128
+    t.join()
+
+
+def test_bench_launches_its_own_ranks_and_reports_a_failed_rank():
+    """`python bench.py --gpus 2` with no launcher in front: the parent (which never touches the GPU) starts the two
+    ranks itself and exits non-zero when one fails -- here both do, there is no GPU (the success path runs in
+    tests/test_gpu_00_multirank.py)."""
+    from spatialcore_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu test of the same launcher")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "1000", "--genes", "4",
+                          "--perms", "10", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert res.returncode == 1
+    assert "bench.py launcher: rank(s)" in res.stderr and "no ROCm-capable device" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -90,6 +90,22 @@ def test_bench_two_rank_rehearsal_prints_one_valid_line(tmp_path):
     assert line["scaling"] == "strong" and line["config"]["genes_total"] == 70 and line["config"]["genes_per_gpu"] == 35
 
 
+def test_bench_launches_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the driver invokes the bench for N = 1, no torchrun in front: the
+    parent starts the two ranks itself (fresh processes; it never touches the GPU) and relays rank 0's one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SC_RENDEZVOUS_FILE")}
+    env["SC_COMM_TIMEOUT_S"] = "240"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--cells", "150000",
+           "--genes", "40", "--perms", "300", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["nccl_ranks"] == 2 and line["config"]["genes_total"] == 80
+    assert line["value"] > 0 and line["permgen_stats"]["verification_fallbacks_max_over_ranks"] == 0
+
+
 def test_rccl_communicator_world_of_one():
     """dlopen(librccl) + ncclGetUniqueId + ncclCommInitRank + ncclAllGather + ncclAllReduce on the real device."""
     from spatialcore_amd._lib import Context, RcclComm
@@ -99,6 +115,8 @@ def test_rccl_communicator_world_of_one():
         block = np.arange(12, dtype=np.float64).reshape(3, 4) * 0.5
         np.testing.assert_array_equal(comm.all_gather(block), block[None])
         np.testing.assert_array_equal(comm.max_over_ranks([1.5, -2.0]), [1.5, -2.0])
+        np.testing.assert_array_equal(comm.sum_over_ranks_i64([[2**60 + 1, -5]]), [[2**60 + 1, -5]])
+        assert comm.info() == (1, 0, 0)                       # ncclCommCount / ncclCommUserRank / ncclCommCuDevice
         comm.barrier()
         comm.close()
     with pytest.raises(ValueError):
