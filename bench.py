@@ -4,10 +4,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one full pass of the hot path over one batch of synthetic input that is already
-resident (coordinates on the host as the API takes them, expression tiles in HBM): exact kNN build,
-row-normalised graph, numpy-exact permutation table for `seed`, lag, the permutation kernel for all
-genes, p-value assembly, and (N > 1) ONE RCCL all-gather of the per-gene results.  Nothing is cached
-between steps.
+resident (coordinates on the host as the API takes them, raw expression tiles in HBM): exact kNN build,
+row-normalised graph, numpy-exact permutation table for `seed`, value classes + centring + the narrow
+copy of the raw values the permutation kernel gathers, lag, the permutation kernel for all genes,
+p-value assembly, and (N > 1) ONE RCCL all-gather of the per-gene results.  Nothing derived is cached
+between steps: only the uploaded inputs (coordinates on the host, raw fp64 tiles on the device) persist.
+
+`value` is that resident-operand step (the contract: inputs in HBM when the timed region starts);
+`value_public_api` is SURVEY 8(d)'s literal metric, G / wall time of morans_i(adata, ...) with host
+arrays in and a DataFrame out.  `value_uint16_source` / `value_float32_source` repeat the step with the
+gathered operand forced to the wider exact types (counts >= 256; log-normalised float matrices).
+
+`python bench.py --gpus N` with no launcher in front starts its own N ranks (launch_ranks).
 
 Workloads
   default          BASELINE.json configs[1] per GPU (1M cells, 500 genes, k=15, P=1000); genes shard across
@@ -116,26 +124,25 @@ def cpu_baseline_and_verify(coords, X, k: int, n_perm_full: int, seed: int, gpu_
             "sample_1_thread": s_1}
 
     # ---- verification of the timed GPU result (2 genes, all P permutations) ----
+    # The bench genes are integer counts on a kNN graph, i.e. lattice genes (DESIGN.md "Ties"): the statistic's
+    # permutation-dependent part is the integer T_p = sum_i x_i S[perm_p(i)], and BOTH sides decide sims >= I on those
+    # integers -- the oracle in int64 (orc.morans_count_ge), the device in exact fp64 -- so the counts must be EQUAL,
+    # exact ties included (41 of the 250 Poisson genes have one among 1000 permutations).  No tolerance.
     cols = list(check_genes)
     vals = np.ascontiguousarray(X[:, cols].T, dtype=np.float64)
     I_ref = orc.morans_i_scores(g, vals)
     sims = orc.morans_i_sims_gather(g, vals, perms)
-    want = (sims >= I_ref).sum(axis=0)
-    # Discrete low-count genes put the statistic on a lattice (sum_j S_j x_perm(j) is an integer), so a permutation can
-    # TIE the observed value in exact arithmetic; every floating-point implementation, the reference's included,
-    # then decides by the rounding noise of its summation order (DESIGN.md "Ties").  A tie = closer than 1e-9 of the
-    # gene's spread over permutations (lattice step ~1e-3 of it, rounding noise of a 1M-term sum ~1e-12 of it).
-    spread = sims.std(axis=0)
-    gap = np.abs(sims - I_ref)
-    ties = (gap <= np.maximum(1e-11 * np.abs(I_ref), 1e-9 * spread)).sum(axis=0)
+    want, lattice = orc.morans_count_ge(g, vals, perms, sims, I_ref)
+    exact_ties = (np.abs(sims - I_ref) <= 1e-9 * sims.std(axis=0)).sum(axis=0)     # reported, no longer tolerated
     I_gpu, c_gpu = gpu_res["I"][cols], gpu_res["count_ge"][cols]
     rel = float(np.max(np.abs(I_gpu - I_ref) / np.abs(I_ref)))
-    ok = bool(rel <= 1e-9 and (np.abs(c_gpu - want) <= ties).all())
+    ok = bool(rel <= 1e-9 and lattice.all() and (c_gpu == want).all())
     verify = {"verified": ok, "genes_checked": cols, "max_rel_err_I": rel,
               "count_ge_gpu": [int(v) for v in c_gpu], "count_ge_oracle": [int(v) for v in want],
-              "exact_ties": [int(v) for v in ties],
-              "nearest_gap_over_spread": [float(v) for v in gap.min(axis=0) / spread],
-              "method": "oracle (cKDTree graph, scalar C numpy-stream model, gather-dot) over all permutations"}
+              "lattice_genes": [bool(v) for v in lattice],
+              "exact_ties_resolved": [int(v) for v in exact_ties],
+              "method": "oracle (cKDTree graph, scalar C numpy-stream model); counts decided on the exact integer "
+                        "lattice T_p >= T_obs on both sides, equality required"}
     return base, verify
 
 
@@ -228,6 +235,8 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline + oracle verification leg")
     ap.add_argument("--no-public-api", action="store_true")
+    ap.add_argument("--no-other-sources", action="store_true",
+                    help="skip the uint16- / float32-source repeats of the step (value_uint16_source, value_float32_source)")
     ap.add_argument("--no-alone", action="store_true",
                     help="skip roofline.alone (counter passes: its launches would be averaged into the per-launch traffic)")
     ap.add_argument("--source-bits", type=int, default=8, choices=(8, 16, 32, 64),
@@ -342,6 +351,7 @@ def main() -> None:
     # The same kernel with the chip to itself (after the timed region, rank 0, single batch): the first 128 permutations
     # of the resident table scored again.  Inside the pipeline it runs on the CUs it leaves to the generator's side
     # and beside the generator's traffic; this is the kernel's own rate.  Reported as roofline.alone, never as `value`.
+    timed_bits = ctx.moran_source_bits()
     alone = None
     if rank == 0 and len(batches) == 1 and not rehearse and P >= 128 and not args.no_alone:
         ctx.reset_timers()
@@ -351,29 +361,57 @@ def main() -> None:
         if a_cnt:
             alone = (a_ms / a_cnt, 128)
 
+    def kernel_roofline(kern_ms, kern_launches, steps, bits):
+        """Bytes the scoring kernel's formulation has to move per launch (its algorithmic bytes) over its average
+        HIP-event launch time.  (1) per step: one 128-byte row of raw values + one 4-byte index per (permutation,
+        cell, gene group of 128 / 64 / 32 / 16 genes) and the fp64 lag rows of every gene once per launch (a launch =
+        one chunk of permutations x all gene groups).  (2) SURVEY 8(d)'s streaming model (16 B per (permutation, gene,
+        cell) + 4 B per (permutation, cell)) as an EFFECTIVE rate: the kernel moves fewer bytes than the model."""
+        genes_per_row = {8: 128, 16: 64, 32: 32, 64: 16}[bits]
+        per_step = max(kern_launches // max(steps, 1), 1)
+        avg = kern_ms / max(kern_launches, 1)
+        g_pad = -(-batch // genes_per_row) * genes_per_row * len(batches)
+        grp = g_pad // genes_per_row
+        step_bytes = grp * (P * n * (128.0 + 4.0)) + per_step * n * 8.0 * g_pad
+        ach = step_bytes / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
+        eff = (P * G_mine * n * 16.0 + P * n * 4.0) / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
+        return {"genes_per_row": genes_per_row, "launches_per_step": per_step, "avg_ms": avg, "g_pad": g_pad, "groups": grp,
+                "step_bytes": step_bytes, "launch_bytes": step_bytes / per_step, "achieved": ach, "effective": eff}
+
+    # The same step with the gathered operand forced to the wider exact types (after the timed region, rank 0, single
+    # batch): what a panel with counts >= 256 (uint16 rows, 64 genes each) or a log-normalised float matrix (float32
+    # rows, 32 genes each) pays.  The statistics are those of the timed run (lattice genes: same integers).
+    other_sources = {}
+    if rank == 0 and world == 1 and len(batches) == 1 and not rehearse and not args.no_other_sources and args.source_bits == 8:
+        for bits_alt in (16, 32):
+            ctx.set_moran_source_bits(bits_alt)
+            step()
+            ctx.sync()
+            ctx.reset_timers()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                res_alt = step()
+            ctx.sync()
+            dt = time.perf_counter() - t1
+            k_ms, k_cnt = ctx.kernel_time(_lib.K_MORAN_PERM)
+            rf = kernel_roofline(k_ms, k_cnt, 3, bits_alt)
+            other_sources[bits_alt] = {
+                "value": G_total * 3 / dt, "ms_per_step": dt / 3 * 1e3, "steps": 3, "source_bits": ctx.moran_source_bits(),
+                "roofline": {"achieved": rf["achieved"], "frac": rf["achieved"] / HBM_PEAK_GBS, "avg_launch_ms": rf["avg_ms"],
+                             "launches": k_cnt, "algorithmic_bytes_per_launch": rf["launch_bytes"],
+                             "step_frac": rf["step_bytes"] / (dt / 3) / 1e9 / HBM_PEAK_GBS},
+                "counts_equal_to_timed_run": bool((res_alt["count_ge"] == res["count_ge"]).all()),
+                "I_equal_to_timed_run": bool((res_alt["I"] == res["I"]).all())}
+        ctx.set_moran_source_bits(args.source_bits)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = G_total * args.steps / elapsed
-        source_bits = ctx.moran_source_bits()
-        kernel_name = {8: "k_moran_score", 16: "k_moran_score", 32: "k_moran_score", 64: "k_moran_perm"}[source_bits]
-        genes_per_launch = {8: 128, 16: 64, 32: 32, 64: 16}[source_bits]   # genes served by one gathered 128-byte row
-        launches_per_step = max(perm_launches // max(args.steps, 1), 1)
-        avg_ms = perm_ms / max(perm_launches, 1)
-        G_pad = -(-batch // genes_per_launch) * genes_per_launch * len(batches)
-        # (1) what THIS kernel's formulation has to move per step (its algorithmic bytes): one 128-byte row of raw
-        #     values and one 4-byte index per (permutation, cell, gene group of 128 / 64 / 32 / 16 genes), and the fp64 lag
-        #     rows of every gene once per launch (a launch = one chunk of permutations x all gene groups for the
-        #     persistent narrow-source kernel, x one 16-gene tile for the fp64 kernel).
-        groups = G_pad // genes_per_launch
-        lag_passes = launches_per_step if source_bits < 64 else launches_per_step / max(groups, 1)
-        kernel_bytes_step = groups * (P * n * (128.0 + 4.0)) + lag_passes * n * 8.0 * G_pad
-        kernel_bytes = kernel_bytes_step / launches_per_step
-        achieved = kernel_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
-        # (2) SURVEY.md 8(d)'s streaming model (the contract's per-unit figure: 16 B per (permutation, gene, cell) for
-        #     fp64 z + gathered fp64 lag, + 4 B per (permutation, cell)) -- an EFFECTIVE rate: the kernel moves fewer
-        #     bytes than the model (float32 32-gene rows, lag shared through the caches), so it can exceed the peak.
-        model_bytes = (P * G_mine * n * 16.0 + P * n * 4.0) / launches_per_step
-        effective = model_bytes / (avg_ms * 1e-3) / 1e9 if perm_launches else 0.0
+        source_bits = timed_bits
+        kernel_name = "k_moran_score"
+        rf = kernel_roofline(perm_ms, perm_launches, args.steps, source_bits)
+        launches_per_step, avg_ms, G_pad, groups = rf["launches_per_step"], rf["avg_ms"], rf["g_pad"], rf["groups"]
+        kernel_bytes, achieved, effective = rf["launch_bytes"], rf["achieved"], rf["effective"]
         # (3) PMC counters of the same kernel build, collected by scripts/pmc_traffic.py (separate --pmc passes)
         traffic, traffic_note = None, "no PMC file for this kernel"
         tpath = os.path.join(ROOT, "profiles", f"{kernel_name}_pmc_traffic.json")
@@ -404,6 +442,8 @@ def main() -> None:
                                    + (f"{G_total} genes in total sharded over {world} GPU(s) in batches of <= {batch}"
                                       if strong else f"{G_mine} genes per GPU")
                                    + f", k={k} kNN, {P} numpy-exact permutations, seed={args.seed}"
+                                   + "; value = the resident-operand step (inputs in HBM), value_public_api = wall time of "
+                                     "morans_i(adata, ...) with host arrays in and a DataFrame out (SURVEY 8(d) literal)"
                                    + (" (BASELINE configs[1])" if (n, genes_arg, P, k, strong) == (1_000_000, 500, 1000, 15, False)
                                       else " (BASELINE configs[3])" if (n, genes_arg, P, k, strong) == (5_000_000, 2000, 1000, 15, True)
                                       else " (non-default size)"),
@@ -415,6 +455,9 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": perm_launches,
                          "algorithmic_bytes_per_launch": kernel_bytes,
+                         "step_frac": rf["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_frac_basis": "the same compulsory bytes of one step / ms_per_step / peak: what the whole "
+                                            "step (graph, generator, lag, scoring, p-values) sustains",
                          "basis": "bytes this kernel's formulation must move (128-B raw-value row + 4-B index per "
                                   "(permutation, cell, tile), lag rows once per launch) / HIP-event launch time",
                          "effective": effective, "effective_frac": effective / HBM_PEAK_GBS,
@@ -437,6 +480,10 @@ def main() -> None:
             "device_mem_bytes_rank0": mem_peak,
             "nccl_ranks": comm_ranks,
         }
+        for bits_alt, name in ((16, "uint16"), (32, "float32")):
+            if bits_alt in other_sources:
+                line[f"value_{name}_source"] = other_sources[bits_alt]["value"]
+                line[f"{name}_source"] = other_sources[bits_alt]
         if fallbacks:
             line["warning"] = "the block-parallel generator fell back to the sequential scan inside the timed region"
         if world == 1 and not strong and not args.no_public_api:

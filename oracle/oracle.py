@@ -335,6 +335,54 @@ def morans_i_sims_gather(g: csr_matrix, vals: np.ndarray, perms: np.ndarray) -> 
     return sims
 
 
+def lattice_genes(g: csr_matrix, vals: np.ndarray) -> np.ndarray:
+    """Genes whose permutation statistic lives on an integer lattice: every value an integer count in [0, 65535] and
+    every stored weight of the graph equal (a kNN graph after l1 row normalisation: 1/k).  With S = A x (A = 0/1
+    adjacency) sum_i z[i] lag[perm[i]] = w (T_perm - mean * sum S) in exact arithmetic, T_perm = sum_i x[i] S[perm[i]]
+    an integer: a permutation can TIE the observed value exactly.  The reference's float loop (scanpy's numba kernel
+    behind AC:576-583) decides such ties by the rounding noise of its summation order -- nothing reproducible; the
+    exact-arithmetic outcome (a tie counts as >=, as `sims >= I` reads) is what this oracle pins."""
+    vals = np.asarray(vals)
+    data = csr_matrix(g).data
+    uniform = data.size > 0 and bool((data == data[0]).all()) and data[0] > 0
+    ok = np.zeros(vals.shape[0], dtype=bool)
+    if uniform:
+        with np.errstate(invalid="ignore"):
+            ok = ((vals >= 0) & (vals <= 65535) & (vals == np.floor(vals))).all(axis=1)
+    return ok
+
+
+def morans_count_ge(g: csr_matrix, vals: np.ndarray, perms: np.ndarray, sims: Optional[np.ndarray] = None,
+                    score: Optional[np.ndarray] = None):
+    """#{p : sims_p >= I} per gene.  Lattice genes (see lattice_genes): decided on the exact integers T_p >= T_obs.
+    Other genes: the float comparison of the gather form.  Returns (count, is_lattice)."""
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    perms = np.ascontiguousarray(perms, dtype=np.int32)
+    lat = lattice_genes(g, vals)
+    if sims is None:
+        sims = morans_i_sims_gather(g, vals, perms)
+    if score is None:
+        score = morans_i_scores(g, vals)
+    with np.errstate(invalid="ignore"):
+        count = (sims >= score).sum(axis=0).astype(np.int64)
+    if lat.any():
+        n = vals.shape[1]
+        A = csr_matrix(g).copy()
+        A.data = np.ones_like(A.data)
+        x = np.ascontiguousarray(vals[lat].astype(np.int64))
+        S = np.ascontiguousarray(np.rint(A @ x.T.astype(np.float64)).T.astype(np.int64))
+        T = np.empty((perms.shape[0], x.shape[0]), dtype=np.int64)
+        T0 = np.empty((1, x.shape[0]), dtype=np.int64)
+        lib = clib()
+        lib.orc_lattice_T(_p(x), _p(S), ctypes.c_int64(n), ctypes.c_int64(x.shape[0]), _p(perms),
+                          ctypes.c_int64(perms.shape[0]), _p(T))
+        lib.orc_lattice_T(_p(x), _p(S), ctypes.c_int64(n), ctypes.c_int64(x.shape[0]), None, ctypes.c_int64(1), _p(T0))
+        exact = (T >= T0).sum(axis=0).astype(np.int64)
+        exact[vals[lat].var(axis=1) == 0] = 0          # zero-variance gene: I is NaN, nothing counts
+        count[lat] = exact
+    return count, lat
+
+
 def analytic_pval(score: np.ndarray, g: csr_matrix) -> Tuple[np.ndarray, float]:
     """[upstream squidpy _analytic_pval, mode='moran', two_tailed=False]."""
     s0, s1, s2 = graph_moments(g)
@@ -350,14 +398,16 @@ def analytic_pval(score: np.ndarray, g: csr_matrix) -> Tuple[np.ndarray, float]:
     return p, float(var_norm)
 
 
-def pvalues_squidpy(score: np.ndarray, sims: Optional[np.ndarray], g: csr_matrix) -> Dict[str, np.ndarray]:
-    """[upstream squidpy _p_value_calc]."""
+def pvalues_squidpy(score: np.ndarray, sims: Optional[np.ndarray], g: csr_matrix,
+                    count_ge: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+    """[upstream squidpy _p_value_calc].  count_ge: #{sims >= score} decided elsewhere (morans_count_ge: exact for
+    lattice genes) instead of by the float comparison."""
     p_norm, var_norm = analytic_pval(score, g)
     res = {"pval_norm": p_norm, "var_norm": np.full(score.shape, var_norm)}
     if sims is None:
         return res
     P = sims.shape[0]
-    large = (sims >= score).sum(axis=0)
+    large = (sims >= score).sum(axis=0) if count_ge is None else np.array(count_ge, dtype=np.int64)
     flip = (P - large) < large
     large[flip] = P - large[flip]
     res["pval_sim"] = (large + 1) / (P + 1)
@@ -383,19 +433,20 @@ def morans_i_reference_table(coords, X, gene_cols, k, n_permutations, seed,
     g = row_normalize_l1(conn)
     vals = dense_genes(X, gene_cols)
     score = morans_i_scores(g, vals)
-    sims = perms = None
+    sims = perms = count_ge = lattice = None
     if n_permutations > 0:
         perms, _ = perm_table(int(seed), n, n_permutations)
         sims = morans_i_sims_literal(g, vals, n_permutations, seed) if literal \
             else morans_i_sims_gather(g, vals, perms)
-    pv = pvalues_squidpy(score, sims, g)
+        count_ge, lattice = morans_count_ge(g, vals, perms, sims, score)
+    pv = pvalues_squidpy(score, sims, g, count_ge)
     expected = -1.0 / (n - 1)
     var_norm = pv["var_norm"]
     z_score = np.where(var_norm > 0, (score - expected) / np.sqrt(np.where(var_norm > 0, var_norm, 1)), 0.0)
     p_value = pv["pval_sim"] if n_permutations > 0 else pv["pval_norm"]
     return {"I": score, "expected_I": np.full(score.shape, expected), "z_score": z_score,
             "p_value": np.asarray(p_value, dtype=np.float64), "sims": sims, "perms": perms,
-            "var_norm": var_norm, "graph": g, "connectivities": conn, **{k_: v for k_, v in pv.items()}}
+            "count_ge": count_ge, "lattice": lattice, "var_norm": var_norm, "graph": g, "connectivities": conn, **{k_: v for k_, v in pv.items()}}
 
 
 # =============================================================================================

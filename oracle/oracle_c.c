@@ -208,6 +208,29 @@ void orc_gather_dot(const double *z, const double *lag, int64_t n, int64_t n_gen
 }
 
 /*
+ * Integer-lattice form of the same sum for integer counts on a graph whose weights are all equal: with S = A x (A = the
+ * 0/1 adjacency) the permutation-dependent part of sum_i z[i] lag[perm[i]] is T = sum_i x[i] * S[perm[i]], an exact
+ * integer.  T[p*G+g]; perm == NULL: identity (the observed statistic).  x, S gene-major [G][n] int64.
+ */
+void orc_lattice_T(const int64_t *x, const int64_t *S, int64_t n, int64_t n_genes, const int32_t *perm,
+                   int64_t n_perm, int64_t *T)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t p = 0; p < n_perm; ++p) {
+        for (int64_t g = 0; g < n_genes; ++g) {
+            const int32_t *pi = perm ? perm + p * n : NULL;
+            const int64_t *xg = x + g * n, *sg = S + g * n;
+            int64_t t = 0;
+            if (pi)
+                for (int64_t i = 0; i < n; ++i) t += xg[i] * sg[pi[i]];
+            else
+                for (int64_t i = 0; i < n; ++i) t += xg[i] * sg[i];
+            T[p * n_genes + g] = t;
+        }
+    }
+}
+
+/*
  * Lee's L permutation loop, reference autocorrelation.py:322-328, literal form:
  * z_y is shuffled by the SAME swaps rng.permutation(z_y) applies, then lag = W @ z_y_perm,
  * L_perm = sum_i z_x[i]*lag[i].  Stream state st[] carries over between calls (one rng for all

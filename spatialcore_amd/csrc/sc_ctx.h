@@ -95,6 +95,8 @@ struct sc_ctx {
     // ---- graph (CSR, rows sorted by column) + transpose ----
     int64_t g_n = 0, g_nnz = 0;
     DBuf g_indptr, g_indices, g_data;
+    double g_uniform_w = 0.0;   // > 0: every stored weight equals this value (kNN graphs: 1 / k); 0: weights differ
+    int64_t g_deg_max = 0;      // longest row
     bool gt_valid = false;
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
     bool s0_valid = false;
@@ -110,15 +112,22 @@ struct sc_ctx {
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // the raw values again in the narrowest exact type, one 128-byte row per cell and gene group:
                          // 32 float (float32-exact values), 64 uint16 (counts < 65536) or 128 uint8 (counts < 256) per row
-    bool x32_valid = false, x32_exact = false;  // the narrow copy was (tried to be) built / is usable
-    int narrow_bits = 64;                       // ... and its element width: 8, 16, 32 (64: none, fp64 tiles only)
+    int narrow_bits = 64;       // element width of the narrow copy the last moran_prepare built: 8, 16, 32 (64: none, the fp64 Z tiles are gathered)
     int n_cus = 0;              // compute units of the device (filled on first use)
     int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
     int source_bits_min = 8;    // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
     int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene
-    DBuf g_slag;         // uint8 source: [sum_j lag_g[j] | mean_g * that] per padded gene
+    DBuf g_slag;         // sum_j lag_g[j] per padded gene (lattice genes: the exact integer sum of the neighbour sums)
+    // Integer-lattice genes (DESIGN.md "Ties"): integer counts on a graph whose weights are all equal.  Their statistic
+    // is scored as the exact integer T_p = sum_j S_j x[inv_p(j)] (S = unweighted neighbour sums; every product and partial
+    // sum is an integer < 2^53, so the fp64 arithmetic is exact in any order) and #{T_p >= T_obs} is decided on integers.
+    DBuf g_xsum, g_flags, g_xmax;      // per padded gene: raw column sum, value-class bits (k_gene_stats), largest count
+    DBuf g_lat, g_meanc, g_seff, g_corr, g_thr;  // lattice flag (0 / 1), mean used for centring (0 for lattice genes),
+                                                 // sims = seff * (sum - corr), threshold the count compares against
+    DBuf sims_raw;                     // the sums themselves (lattice genes: T_p), same layout as sims
+    bool lat_any = false;
 
     // ---- permutation table ----
     int64_t p_n = 0, p_count = 0, p_stride = 0;  // row stride in elements (multiple of 32)

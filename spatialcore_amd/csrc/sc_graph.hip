@@ -496,8 +496,17 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL && nnz >= 0, SC_ERR_INVALID, "sc_graph_set_csr: bad shape");
     SC_REQUIRE(nnz == 0 || (indices && data), SC_ERR_INVALID, "sc_graph_set_csr: null indices/data");
     SC_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, SC_ERR_INVALID, "sc_graph_set_csr: indptr does not span nnz");
-    for (int64_t i = 0; i < n; ++i)
+    int64_t deg_max = 0;
+    for (int64_t i = 0; i < n; ++i) {
         SC_REQUIRE(indptr[i + 1] >= indptr[i], SC_ERR_INVALID, "sc_graph_set_csr: indptr not monotone");
+        if (indptr[i + 1] - indptr[i] > deg_max) deg_max = indptr[i + 1] - indptr[i];
+    }
+    // all weights equal (a kNN graph after row normalisation: 1 / k)?  Integer-count genes then sit on an integer
+    // lattice and their permutation counts are decided exactly (sc_moran.hip, "lattice genes")
+    double uniform_w = nnz > 0 ? data[0] : 0.0;
+    for (int64_t e = 1; e < nnz && uniform_w != 0.0; ++e)
+        if (data[e] != uniform_w) uniform_w = 0.0;
+    if (!(uniform_w > 0.0) || uniform_w > 1e300) uniform_w = 0.0;
     SC_HIP(hipSetDevice(c->device));
     c->g_n = 0;
     c->gt_valid = false;
@@ -524,6 +533,8 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     SC_TRY(sc_graph_capture_order(c, n));
     c->g_n = n;
     c->g_nnz = nnz;
+    c->g_uniform_w = uniform_w;
+    c->g_deg_max = deg_max;
     return SC_OK;
 }
 
@@ -566,6 +577,8 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
     SC_HIP(hipStreamSynchronize(c->stream));
     c->g_n = n;
     c->g_nnz = nnz;
+    c->g_uniform_w = (weight > 0.0 && weight < 1e300) ? weight : 0.0;
+    c->g_deg_max = c->knn_k;
     return SC_OK;
 }
 

@@ -72,12 +72,14 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     SC_TRY(c->g_z2.ensure(gb, &c->mem));
     SC_TRY(c->g_scale.ensure(gb, &c->mem));
     SC_TRY(c->g_Inum.ensure(gb, &c->mem));
+    SC_TRY(c->g_xsum.ensure(gb, &c->mem));
+    SC_TRY(c->g_meanc.ensure(gb, &c->mem));
+    SC_TRY(c->g_lat.ensure(gb, &c->mem));
     c->e_n = n;
     c->e_genes = n_genes;
     c->e_tiles = tiles;
-    c->x32_valid = false;
-    c->x32_exact = false;
     c->narrow_bits = 64;
+    c->lat_any = false;
     c->lm_valid = false;
     return SC_OK;
 }
@@ -196,11 +198,12 @@ extern "C" int sc_expr_set_dense(sc_ctx *c, const void *data, int dtype, int64_t
 // per-gene column reductions over tiles (deterministic two-stage tree)
 // ------------------------------------------------------------------------------------------------
 
-enum { OP_ID = 0, OP_SQ = 1, OP_MUL = 2, OP_NZ = 3 };
+enum { OP_ID = 0, OP_SQ = 1, OP_MUL = 2, OP_NZ = 3, OP_SQC = 4 };
 
 #define RED_ROWS_PER_BLOCK 4096
 
 // partial[tile][chunk][16] = sum over the chunk's rows of op(A[row][slot], B[row][slot])
+// (OP_SQC: (A[row][slot] - B[tile * 16 + slot])^2, B = the per-gene means: the squares of Z = X - mean without storing Z)
 template <int OP>
 __global__ __launch_bounds__(256) void k_colsum_partial(const double *__restrict__ A,
                                                         const double *__restrict__ B,
@@ -211,12 +214,14 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const double *__restrict
     const int slot = threadIdx.x & 15, rg = threadIdx.x >> 4;  // 16 row groups
     const double *a = A + tile * n * SC_TILE;
     const double *b = (OP == OP_MUL) ? B + tile * n * SC_TILE : nullptr;
+    const double centre = (OP == OP_SQC) ? B[tile * SC_TILE + slot] : 0.0;
     int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK;
     int64_t r1 = r0 + RED_ROWS_PER_BLOCK < n ? r0 + RED_ROWS_PER_BLOCK : n;
     double acc = 0.0;
     for (int64_t r = r0 + rg; r < r1; r += 16) {
         double v = a[r * SC_TILE + slot];
-        if (OP == OP_SQ) v = v * v;
+        if (OP == OP_SQC) v = v - centre;
+        if (OP == OP_SQ || OP == OP_SQC) v = v * v;
         if (OP == OP_NZ) v = (v != 0.0) ? 1.0 : 0.0;
         if (OP == OP_MUL) v = v * b[r * SC_TILE + slot];
         acc += v;
@@ -281,20 +286,33 @@ __global__ __launch_bounds__(256) void k_div_sd(double *__restrict__ Z, const do
     Z[tile * n * SC_TILE + t] = (v > 0.0) ? Z[tile * n * SC_TILE + t] / sd : 0.0;
 }
 
+// mean (+ raw column sums), z2 = sum (X - mean)^2, var = z2 / n
+static int expr_moments(sc_ctx *c)
+{
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "no expression loaded (call sc_expr_set_* first)");
+    const int64_t n = c->e_n;
+    SC_TRY(colsum<OP_ID>(c, c->X.as<double>(), nullptr, c->g_mean.as<double>(), (double)n, c->g_xsum.as<double>()));
+    SC_TRY(colsum<OP_SQC>(c, c->X.as<double>(), c->g_mean.as<double>(), c->g_var.as<double>(), (double)n, c->g_z2.as<double>()));
+    return SC_OK;
+}
+
+// Z = X - centre (per gene)
+static int expr_write_z(sc_ctx *c, const double *centre)
+{
+    c->lm_valid = false;  // Z is about to be rewritten
+    const int64_t n = c->e_n;
+    SC_TRY(c->Z.ensure((size_t)c->e_tiles * n * SC_TILE * sizeof(double), &c->mem));
+    dim3 grid((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)c->e_tiles);
+    hipLaunchKernelGGL(k_center, grid, dim3(256), 0, c->stream, c->X.as<double>(), centre, c->Z.as<double>(), n);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 // mean, Z = X - mean, z2 = sum Z^2, var = z2 / n
 static int expr_center(sc_ctx *c)
 {
-    c->lm_valid = false;  // Z is about to be rewritten
-    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "no expression loaded (call sc_expr_set_* first)");
-    int64_t n = c->e_n;
-    SC_TRY(c->Z.ensure((size_t)c->e_tiles * n * SC_TILE * sizeof(double), &c->mem));
-    SC_TRY(colsum<OP_ID>(c, c->X.as<double>(), nullptr, c->g_mean.as<double>(), (double)n));
-    dim3 grid((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)c->e_tiles);
-    hipLaunchKernelGGL(k_center, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->g_mean.as<double>(),
-                       c->Z.as<double>(), n);
-    SC_TRY(colsum<OP_SQ>(c, c->Z.as<double>(), nullptr, c->g_var.as<double>(), (double)n, c->g_z2.as<double>()));
-    SC_HIP(hipGetLastError());
-    return SC_OK;
+    SC_TRY(expr_moments(c));
+    return expr_write_z(c, c->g_mean.as<double>());
 }
 
 extern "C" int sc_expr_stats(sc_ctx *c, double *mean_out, double *var_out)
@@ -317,10 +335,12 @@ extern "C" int sc_expr_stats(sc_ctx *c, double *mean_out, double *var_out)
 // separately, like scanpy's `(i_data * z[i_indices]).sum()` and scipy's csr_matvec)
 // ------------------------------------------------------------------------------------------------
 
+// unit[gene] != 0 (optional): the gene's rows are summed with weight 1 instead of w[e] -- the unweighted neighbour sums S
+// of an integer-lattice gene (Z holds its raw counts then), exact integers in fp64
 __global__ __launch_bounds__(256) void k_lag(const int64_t *__restrict__ indptr,
                                              const int32_t *__restrict__ indices,
                                              const double *__restrict__ w, const double *__restrict__ Z,
-                                             double *__restrict__ Lag, int64_t n)
+                                             double *__restrict__ Lag, int64_t n, const double *__restrict__ unit)
 {
     // 8 threads per cell, each owning 2 of the tile's 16 genes (one 16-byte slice of the row)
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,25 +349,27 @@ __global__ __launch_bounds__(256) void k_lag(const int64_t *__restrict__ indptr,
     if (i >= n) return;
     const double2 *Zt = reinterpret_cast<const double2 *>(Z + (int64_t)blockIdx.y * n * SC_TILE);
     double2 *Lt = reinterpret_cast<double2 *>(Lag + (int64_t)blockIdx.y * n * SC_TILE);
+    const bool ux = unit && unit[(int64_t)blockIdx.y * SC_TILE + 2 * q] != 0.0;
+    const bool uy = unit && unit[(int64_t)blockIdx.y * SC_TILE + 2 * q + 1] != 0.0;
     int64_t e0 = indptr[i], e1 = indptr[i + 1];
     double sx = 0.0, sy = 0.0;
     for (int64_t e = e0; e < e1; ++e) {
         int32_t j = indices[e];
         double ww = w[e];
         double2 z = Zt[(int64_t)j * 8 + q];
-        sx = __dadd_rn(sx, __dmul_rn(ww, z.x));
-        sy = __dadd_rn(sy, __dmul_rn(ww, z.y));
+        sx = __dadd_rn(sx, __dmul_rn(ux ? 1.0 : ww, z.x));
+        sy = __dadd_rn(sy, __dmul_rn(uy ? 1.0 : ww, z.y));
     }
     Lt[i * 8 + q] = make_double2(sx, sy);
 }
 
 static int launch_lag(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const DBuf &data, const double *Z,
-                      double *out)
+                      double *out, const double *unit = nullptr)
 {
     int64_t n = c->e_n;
     KernelTimerScope ts(c, SC_K_LAG);
     hipLaunchKernelGGL(k_lag, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)c->e_tiles), dim3(256), 0,
-                       c->stream, indptr.as<int64_t>(), indices.as<int32_t>(), data.as<double>(), Z, out, n);
+                       c->stream, indptr.as<int64_t>(), indices.as<int32_t>(), data.as<double>(), Z, out, n, unit);
     SC_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -444,10 +466,10 @@ __global__ __launch_bounds__(256) void k_moran_perm(const double *__restrict__ Z
     }
 }
 
-// sims[p0 + p][g0 + slot] = scale[slot] * sum_s partial[s][p][slot]   (ascending s)
+// sims[p0 + p][g0 + slot] = seff * (sum_s partial[s][p][slot] - corr)   (ascending s); raw = the sum itself
 __global__ __launch_bounds__(256) void k_moran_finalize(const double *__restrict__ partial,
-                                                        const double *__restrict__ scale,
-                                                        double *__restrict__ sims, int n_perm, int splits,
+                                                        const double *__restrict__ seff, const double *__restrict__ corr,
+                                                        double *__restrict__ sims, double *__restrict__ raw, int n_perm, int splits,
                                                         int64_t n_genes, int64_t g0, int64_t p0)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -455,35 +477,51 @@ __global__ __launch_bounds__(256) void k_moran_finalize(const double *__restrict
     if (p >= n_perm || g0 + slot >= n_genes) return;
     double s = 0.0;
     for (int k = 0; k < splits; ++k) s += partial[((int64_t)k * n_perm + p) * SC_TILE + slot];
-    sims[(p0 + p) * n_genes + g0 + slot] = scale[slot] * s;
+    raw[(p0 + p) * n_genes + g0 + slot] = s;
+    sims[(p0 + p) * n_genes + g0 + slot] = seff[g0 + slot] * (s - corr[g0 + slot]);
 }
 
-// per gene: I = scale * Inum; scale = n / s0 / z2
-__global__ void k_moran_scale(const double *__restrict__ z2, const double *__restrict__ inum,
-                              double *__restrict__ scale, double *__restrict__ I, double n_over_s0, int64_t total)
+// Per gene: how a sum over the cells becomes the statistic, and what the permutation count compares.
+//   ordinary gene: sum = sum_j lag_j z_j;  seff = n / s0 / z2, corr = 0, I = seff * sum, count: sims >= I
+//   lattice gene (integer counts, every graph weight = w): sum = T = sum_j S_j x_j, an exact integer (S = unweighted
+//     neighbour sums); sum_j lag_j z_j = w (T - mean * sum_j S_j) in exact arithmetic, so seff = n / s0 / z2 * w,
+//     corr = mean * sum_j S_j, I = seff * (T_obs - corr), and the count compares the integers: T_p >= T_obs
+__global__ void k_moran_scale(const double *__restrict__ z2, const double *__restrict__ inum, const double *__restrict__ slag,
+                              const double *__restrict__ mean, const double *__restrict__ lat, double *__restrict__ seff,
+                              double *__restrict__ corr, double *__restrict__ thr, double *__restrict__ I, double n_over_s0,
+                              double w, int64_t total)
 {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
-    double sc = n_over_s0 / z2[g];
-    scale[g] = sc;
-    I[g] = sc * inum[g];
+    const bool l = lat[g] != 0.0;
+    const double sc = l ? (n_over_s0 / z2[g]) * w : n_over_s0 / z2[g];
+    const double co = l ? mean[g] * slag[g] : 0.0;
+    const double v = sc * (inum[g] - co);
+    seff[g] = sc;
+    corr[g] = co;
+    I[g] = v;
+    thr[g] = l ? inum[g] : v;
 }
 
-// per gene: count(sims >= I), sum sims, sum sims^2 over permutations (block per gene, fixed tree)
-__global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ sims,
-                                                     const double *__restrict__ I, int n_perm,
+// per gene: count(sims >= I) -- for lattice genes count(T_p >= T_obs), on the exact integer sums --, sum sims,
+// sum sims^2 over permutations (block per gene, fixed tree).  A zero-variance gene (I = NaN) counts nothing.
+__global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ sims, const double *__restrict__ raw,
+                                                     const double *__restrict__ thr, const double *__restrict__ lat,
+                                                     const double *__restrict__ z2, int n_perm,
                                                      int64_t n_genes, long long *__restrict__ count,
                                                      double *__restrict__ ssum, double *__restrict__ ssq)
 {
     __shared__ double sh_a[256], sh_b[256];
     __shared__ int sh_c[256];
     int64_t g = blockIdx.x;
-    double obs = I[g];
+    const double t = thr[g];
+    const bool l = lat[g] != 0.0, alive = z2[g] > 0.0;
     double a = 0.0, b = 0.0;
     int cnt = 0;
     for (int p = threadIdx.x; p < n_perm; p += 256) {
         double v = sims[(int64_t)p * n_genes + g];
-        cnt += (v >= obs) ? 1 : 0;
+        const double cv = l ? raw[(int64_t)p * n_genes + g] : v;
+        cnt += (alive && cv >= t) ? 1 : 0;
         a += v;
         b += v * v;
     }
@@ -507,21 +545,33 @@ __global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// A5 on the narrowest exact copy of the raw values: the same statistic summed over the TARGET cell,
+// A5: the permutation statistic, summed over the TARGET cell,
 //
-//   sims[p][g] = scale_g * sum_j lag_g[j] * z_g[inv_p[j]],   inv_p = perm_p^-1,   z = (double)x - mean
+//   sims[p][g] = scale_g * sum_j lag_g[j] * z_g[inv_p[j]],   inv_p = perm_p^-1,   z = (double)x - centre_g
 //
-// z is rebuilt in registers from the raw value x: (double)x - mean is the very subtraction k_center performs, so
-// every product is bit-identical to the fp64-tile kernel's.  The gathered operand is a 128-byte row of
-//   * 128 uint8 genes when every loaded value is an integer count in [0, 255]     (BITS = 8; sums lag * x, the term
-//     mean * sum(lag) is taken off per statistic in the finalisation: 16 accumulators leave no registers for 16 means),
-//   * 64 uint16 genes when every loaded value is an integer count in [0, 65535]   (BITS = 16), else
-//   * 32 float32 genes when every value is a float32 (AnnData's usual dtype)       (BITS = 32),
-// instead of 16 fp64 genes: an eighth / quarter / half of the random-row bytes per gene.  The fp64 lag rows are the
-// streamed, coalesced operand and the INVERSE permutation supplies the gather index.
+// The fp64 lag rows are the streamed, coalesced operand; the INVERSE permutation supplies the gather index; the
+// gathered operand is a 128-byte row of the raw values in the narrowest type that holds EVERY loaded gene exactly:
+//   * 128 uint8 genes  (BITS = 8)   every value an integer count in [0, 255] and every gene a lattice gene (below),
+//   * 64 uint16 genes  (BITS = 16)  every value an integer count in [0, 65535],
+//   * 32 float32 genes (BITS = 32)  every value a float32 (AnnData's usual dtype),
+//   * 16 fp64 genes    (BITS = 64)  anything else: the rows of the Z tiles themselves.
+// z is rebuilt in registers: (double)x - centre is the very subtraction k_center performs for the Z tiles, and every
+// width adds the same products in the same order (cells ascending inside a split, splits ascending in the
+// finalisation) -- A GENE'S STATISTICS DO NOT DEPEND ON THE WIDTH, i.e. not on the genes it is loaded with.
+//
+// Lattice genes (integer counts on a graph whose weights all equal w, e.g. kNN: w = 1 / k): lag_j = w S_j - mean with
+// the integer neighbour sum S_j, so the part of the statistic that depends on the permutation is T_p = sum_j S_j x[inv_p[j]],
+// an integer, and a permutation can TIE the observed value exactly (41 of 250 Poisson genes of the bench matrix have
+// such a permutation among 1000).  Rounded lag / z operands decide those ties by summation-order noise -- the
+// reference's numba loop as much as any kernel here.  They are therefore scored on the lattice itself: centre = 0,
+// streamed operand = S (k_lag with unit weights).  Every product and partial sum is an integer below 2^53 (checked on
+// the host: max degree * largest count * sum of counts), so the fp64 arithmetic is EXACT in any order, and the
+// permutation count is #{T_p >= T_obs} on integers (k_moran_scale / k_moran_count turn T into I and sims).
+// The uint8 kernel has no registers for 16 centres next to its 16 accumulators; it is used when every loaded gene is a
+// lattice gene (centre 0); uint8-sized counts on a graph with unequal weights take the uint16 kernel.
 //
 // Row layout (all widths): the 8 lanes q that share a row own genes {16 t + 2 q, 16 t + 2 q + 1 : t < TG} of the
-// group's TG 16-gene tiles (TG = 8 / 4 / 2), stored as the lane's 16 bytes [t][e]: a lane's lag operands are then TG
+// group's TG 16-gene tiles (TG = 8 / 4 / 2 / 1), stored as the lane's 16 bytes [t][e]: a lane's lag operands are then TG
 // 16-byte LDS reads that are contiguous across q (no bank conflicts), one per lag tile.
 //
 // What bounds the uint8 form (r02, 1M cells, 128 genes x 128 permutations, 3.56 ms on 248 CUs; diagnostic builds
@@ -530,10 +580,54 @@ __global__ __launch_bounds__(256) void k_moran_count(const double *__restrict__ 
 // lag rows and indices ~5.7 TB/s memory-side: the random 128-byte gather at what the fabric sustains.
 // ------------------------------------------------------------------------------------------------
 
-// Narrow[group][cell][q][t][e] = X[TG * group + t][cell][2 q + e] as uint16 / float; *inexact |= a value does not fit
+// Value class of every gene in one pass over the tiles: flags[g] bit 0 = some value is not an integer in [0, 255],
+// bit 1 = ... not an integer in [0, 65535], bit 2 = ... not a float32 (NaN included); xmax[g] = largest integer count
+// (0xffffffff as soon as a value is no integer in [0, 2^32))
+__global__ __launch_bounds__(256) void k_gene_stats(const double *__restrict__ X, int64_t n, uint32_t *__restrict__ flags,
+                                                    uint32_t *__restrict__ xmax)
+{
+    __shared__ uint32_t sh_f[256], sh_m[256];
+    const int64_t tile = blockIdx.y;
+    const int slot = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const double *a = X + tile * n * SC_TILE;
+    const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + RED_ROWS_PER_BLOCK < n ? r0 + RED_ROWS_PER_BLOCK : n;
+    uint32_t f = 0u, m = 0u;
+    for (int64_t r = r0 + rg; r < r1; r += 16) {
+        const double v = a[r * SC_TILE + slot];
+        const bool isint = v >= 0.0 && v <= 4294967295.0 && (double)(uint32_t)v == v;
+        const uint32_t u = isint ? (uint32_t)v : 0xffffffffu;
+        f |= (u <= 255u ? 0u : 1u) | (u <= 65535u ? 0u : 2u) | ((double)(float)v == v ? 0u : 4u);
+        m = u > m ? u : m;
+    }
+    sh_f[threadIdx.x] = f;
+    sh_m[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s >= 16; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh_f[threadIdx.x] |= sh_f[threadIdx.x + s];
+            sh_m[threadIdx.x] = sh_m[threadIdx.x] > sh_m[threadIdx.x + s] ? sh_m[threadIdx.x] : sh_m[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) {
+        if (sh_f[threadIdx.x]) atomicOr(&flags[tile * SC_TILE + threadIdx.x], sh_f[threadIdx.x]);
+        atomicMax(&xmax[tile * SC_TILE + threadIdx.x], sh_m[threadIdx.x]);
+    }
+}
+
+// centre[g] = lat[g] ? 0 : mean[g]
+__global__ void k_moran_centres(const double *__restrict__ mean, const double *__restrict__ lat, double *__restrict__ centre,
+                                int64_t total)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < total) centre[g] = lat[g] != 0.0 ? 0.0 : mean[g];
+}
+
+// Narrow[group][cell][q][t][e] = X[TG * group + t][cell][2 q + e] as uint8 / uint16 / float (every value fits: k_gene_stats)
 template <int BITS>
 __global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ X, uint4 *__restrict__ out, int64_t n,
-                                                     int64_t tiles16, int *__restrict__ inexact)
+                                                     int64_t tiles16)
 {
     constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : 2;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (cell, q)
@@ -541,7 +635,6 @@ __global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ 
     const int64_t cell = t >> 3;
     const int q = (int)(t & 7);
     uint32_t o[4] = {0u, 0u, 0u, 0u};
-    bool bad = false;
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) {
         const int64_t t16 = TG * (int64_t)blockIdx.y + tt;
@@ -549,20 +642,16 @@ __global__ __launch_bounds__(256) void k_pack_narrow(const double *__restrict__ 
         const double2 v = reinterpret_cast<const double2 *>(X + t16 * n * SC_TILE + cell * SC_TILE)[q];
         if (BITS == 8) {
             const uint32_t a = (uint32_t)(v.x >= 0.0 && v.x <= 255.0 ? v.x : 0.0), b = (uint32_t)(v.y >= 0.0 && v.y <= 255.0 ? v.y : 0.0);
-            bad |= (double)a != v.x || (double)b != v.y;
             o[tt >> 1] |= (a | (b << 8)) << (16 * (tt & 1));
         } else if (BITS == 16) {
             const uint32_t a = (uint32_t)(v.x >= 0.0 && v.x <= 65535.0 ? v.x : 0.0), b = (uint32_t)(v.y >= 0.0 && v.y <= 65535.0 ? v.y : 0.0);
-            bad |= (double)a != v.x || (double)b != v.y;   // NaN, negative, fractional or too large
             o[tt] = a | (b << 16);
         } else {
             const float a = (float)v.x, b = (float)v.y;
-            bad |= (double)a != v.x || (double)b != v.y;   // (NaN compares unequal: a NaN matrix takes the fp64 kernel)
             o[2 * tt] = __float_as_uint(a);
             o[2 * tt + 1] = __float_as_uint(b);
         }
     }
-    if (bad) atomicOr(inexact, 1);
     out[((int64_t)blockIdx.y * n + cell) * 8 + q] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
@@ -625,19 +714,20 @@ __global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict
 
 #define SCORE_WAVES 16
 
-template <int BITS, int CB>
+template <int BITS, int CB, bool BIG>
 __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
     int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
 {
-    static_assert((BITS == 8 || BITS == 16 || BITS == 32) && (CB == 4 || CB == 8), "source width / block size");
-    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : 2;   // 16-gene lag tiles per gene group
-    // BITS == 8 (128 genes per row, 16 accumulators per lane): no room for the 16 means in registers -- the raw values
-    // are multiplied as they are, sum_j lag[j] * x[inv[j]], and mean * sum_j lag[j] is taken off in the finalisation
-    // (the same number up to rounding: |mean| / sd <= ~16 for counts <= 255, i.e. ~1e-12 relative on the sums)
-    constexpr bool CENTER = BITS != 8;
+    static_assert((BITS == 8 || BITS == 16 || BITS == 32 || BITS == 64) && (CB == 4 || CB == 8), "source width / block size");
+    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : BITS == 32 ? 2 : 1;   // 16-gene lag tiles per gene group
+    // BITS == 8 (128 genes per row, 16 accumulators per lane): no room for 16 centres in registers -- only launched when
+    // every gene of the batch is a lattice gene (centre 0, integer operands: exact).  BITS == 64 gathers rows of the Z
+    // tiles, which are centred already.
+    constexpr bool CENTER = BITS == 16 || BITS == 32;
     constexpr int ROW = TG * 8;                  // 16-byte pieces of a group's lag row (one cell)
+    static_assert((CB * ROW) % 64 == 0, "a block's lag rows are loaded by whole wavefront instructions");
     constexpr int NI = CB / 4;                   // index vectors per block
     constexpr int NL = CB * ROW / 64;            // lag pieces per lane and block
     constexpr int CSTEP = 64 / ROW;              // cells covered by one cooperative lag load
@@ -663,10 +753,13 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
         if (c1 > n) c1 = n;
         const int32_t *irow = inv + (int64_t)pc * pstride;
         // row i of the group's table at byte offset 128 i (+ 16 q for this lane): a 32-bit offset from a
-        // wavefront-uniform base (n < 2^25 cells, checked by the host), i.e. no 64-bit address arithmetic per gather
+        // wavefront-uniform base (n < 2^25 cells, else the host picks the BIG form), i.e. no 64-bit address arithmetic per gather
         const char *Xg = reinterpret_cast<const char *>(narrow + (int64_t)grp * n * 8);
         const uint32_t qoff = (uint32_t)q * 16u;
-        auto row_of = [&](int32_t i) { return *reinterpret_cast<const uint4 *>(Xg + ((uint32_t)i * 128u + qoff)); };
+        auto row_of = [&](int32_t i) {
+            if constexpr (BIG) return *reinterpret_cast<const uint4 *>(Xg + ((uint64_t)(uint32_t)i * 128u + qoff));
+            else return *reinterpret_cast<const uint4 *>(Xg + ((uint32_t)i * 128u + qoff));
+        };
         const int tiles_left = tiles16 - TG * grp;                                 // lag tiles this group really has
         const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
         // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
@@ -733,7 +826,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
                     v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
 #endif
                 } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
-                else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                else if (BITS == 32) { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                else { v0 = __hiloint2double((int)w[1], (int)w[0]); v1 = __hiloint2double((int)w[3], (int)w[2]); }
                 if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
                 acc[t][0] = fma(l.x, v0, acc[t][0]);
                 acc[t][1] = fma(l.y, v1, acc[t][1]);
@@ -783,7 +877,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
                     const uint32_t h = w[t >> 1] >> (16 * (t & 1));
                     v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
                 } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
-                else { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                else if (BITS == 32) { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                else { v0 = __hiloint2double((int)w[1], (int)w[0]); v1 = __hiloint2double((int)w[3], (int)w[2]); }
                 if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
                 acc[t][0] = fma(l.x, v0, acc[t][0]);
                 acc[t][1] = fma(l.y, v1, acc[t][1]);
@@ -798,15 +893,15 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     }
 }
 
-// sims[p0 + p][GP grp + slot] = scale * sum_s partial[grp][s][p][slot] (ascending s), for every gene group of a
-// chunk in one launch (GP = genes per group: 64 for the uint16 source, 32 for float32)
-// (corr != nullptr: the uint8 kernel summed lag * x, not lag * (x - mean): corr[g] = mean[g] * sum_j lag_g[j] is taken off)
+// sims[p0 + p][GP grp + slot] = seff * (sum_s partial[grp][s][p][slot] - corr) (ascending s), raw = the sum itself, for
+// every gene group of a chunk in one launch (GP = genes per group: 128 / 64 / 32 / 16 by source width); seff, corr:
+// k_moran_scale
 template <int GP>
 __global__ __launch_bounds__(256) void k_moran_finalize_groups(const double *__restrict__ partial,
-                                                               const double *__restrict__ scale,
+                                                               const double *__restrict__ seff,
                                                                const double *__restrict__ corr,
-                                                               double *__restrict__ sims, int n_perm, int splits,
-                                                               int64_t n_genes, int64_t p0)
+                                                               double *__restrict__ sims, double *__restrict__ raw, int n_perm,
+                                                               int splits, int64_t n_genes, int64_t p0)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t / GP, slot = t % GP;
@@ -815,15 +910,8 @@ __global__ __launch_bounds__(256) void k_moran_finalize_groups(const double *__r
     const double *pt = partial + (int64_t)blockIdx.y * splits * n_perm * GP;
     double s = 0.0;
     for (int k = 0; k < splits; ++k) s += pt[((int64_t)k * n_perm + p) * GP + slot];
-    if (corr) s -= corr[g];
-    sims[(p0 + p) * n_genes + g] = scale[g] * s;
-}
-
-// corr[g] = mean[g] * slag[g]
-__global__ void k_mean_times(const double *__restrict__ mean, const double *__restrict__ slag, double *__restrict__ corr, int64_t total)
-{
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < total) corr[g] = mean[g] * slag[g];
+    raw[(p0 + p) * n_genes + g] = s;
+    sims[(p0 + p) * n_genes + g] = seff[g] * (s - corr[g]);
 }
 
 // cell range of one scoring task: a function of n ALONE (results must not depend on the chunking of the
@@ -860,60 +948,87 @@ static int moran_check(sc_ctx *c, int64_t n_perm, const double *I_out)
     return SC_OK;
 }
 
-// z = x - mean, lag = W z, I = n/s0 * sum z*lag / sum z^2 (device), sims buffer sized for n_perm
-static int moran_prepare(sc_ctx *c, int64_t n_perm)
+// Everything the permutation kernels need, from the loaded tiles and the active graph:
+//   value class + lattice decision per gene (one pass + one host sync), Z = X - centre, Lag = W Z (lattice genes: the
+//   unweighted neighbour sums of the raw counts), I, the per-gene finalisation constants, the narrow copy of the batch.
+// allow_lattice = false: ordinary arithmetic for every gene (tables that are not permutations: the identity
+// sum_j x[idx[j]] = sum_j x[j] behind the lattice form does not hold for them).
+static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
 {
-    const int64_t n = c->e_n, T = c->e_tiles;
+    const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
+    const int64_t Tpad = align_up64(T, 8), Gpad = Tpad * SC_TILE;
     SC_TRY(sc_graph_ensure_s0(c));
-    SC_TRY(expr_center(c));
+    SC_TRY(expr_moments(c));
+    // ---- value classes ----
+    SC_TRY(c->g_flags.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem));
+    SC_TRY(c->g_xmax.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem));
+    SC_HIP(hipMemsetAsync(c->g_flags.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream));
+    SC_HIP(hipMemsetAsync(c->g_xmax.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream));
+    hipLaunchKernelGGL(k_gene_stats, dim3((unsigned)ceil_div64(n, RED_ROWS_PER_BLOCK), (unsigned)T), dim3(256), 0, c->stream,
+                       c->X.as<double>(), n, c->g_flags.as<uint32_t>(), c->g_xmax.as<uint32_t>());
+    SC_HIP(hipGetLastError());
+    std::vector<uint32_t> flags((size_t)Gpad), xmax((size_t)Gpad);
+    std::vector<double> xsum((size_t)(T * SC_TILE)), lat((size_t)Gpad, 0.0);
+    SC_HIP(hipMemcpyAsync(flags.data(), c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(xmax.data(), c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(xsum.data(), c->g_xsum.p, sizeof(double) * xsum.size(), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    int bits = c->source_bits_min;
+    bool lat_any = false, lat_all = true;
+    const bool lattice_graph = allow_lattice && c->g_uniform_w > 0.0;
+    for (int64_t g = 0; g < G; ++g) {
+        const int cls = !(flags[(size_t)g] & 1u) ? 8 : !(flags[(size_t)g] & 2u) ? 16 : !(flags[(size_t)g] & 4u) ? 32 : 64;
+        if (cls > bits) bits = cls;
+        // every partial sum of T_p = sum_j S_j x[inv_p(j)] stays an integer below 2^53: T <= max_j S_j * sum x
+        const bool l = lattice_graph && cls <= 16 &&
+                       (double)c->g_deg_max * (double)xmax[(size_t)g] * xsum[(size_t)g] < 4.0e15;
+        lat[(size_t)g] = l ? 1.0 : 0.0;
+        lat_any |= l;
+        lat_all &= l;
+    }
+    if (bits == 8 && !lat_all) bits = 16;      // the uint8 kernel does not centre
+    if (n >= ((int64_t)1 << 25)) bits = 64;    // (rows beyond a 32-bit byte offset: the fp64-row kernel with 64-bit addresses)
+    c->narrow_bits = bits;
+    c->lat_any = lat_any;
+    SC_HIP(hipMemcpyAsync(c->g_lat.p, lat.data(), sizeof(double) * (size_t)Gpad, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_moran_centres, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
+                       c->g_mean.as<double>(), c->g_lat.as<double>(), c->g_meanc.as<double>(), T * SC_TILE);
+    // ---- operands ----
+    SC_TRY(expr_write_z(c, c->g_meanc.as<double>()));
     SC_TRY(c->Lag.ensure((size_t)T * n * SC_TILE * sizeof(double), &c->mem));
-    SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>()));
+    SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>(),
+                      lat_any ? c->g_lat.as<double>() : nullptr));
     SC_TRY(colsum<OP_MUL>(c, c->Z.as<double>(), c->Lag.as<double>(), c->g_Inum.as<double>(), 1.0));
+    const size_t gb = (size_t)Gpad * sizeof(double);
+    SC_TRY(c->g_slag.ensure(gb, &c->mem));
+    SC_TRY(c->g_seff.ensure(gb, &c->mem));
+    SC_TRY(c->g_corr.ensure(gb, &c->mem));
+    SC_TRY(c->g_thr.ensure(gb, &c->mem));
+    SC_TRY(c->g_I.ensure(gb, &c->mem));
+    if (lat_any) SC_TRY(colsum<OP_ID>(c, c->Lag.as<double>(), nullptr, c->g_slag.as<double>(), 1.0));
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(T * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1), &c->mem));
-    SC_TRY(c->g_I.ensure(sizeof(double) * (size_t)T * SC_TILE, &c->mem));
     hipLaunchKernelGGL(k_moran_scale, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
-                       c->g_z2.as<double>(), c->g_Inum.as<double>(), c->g_scale.as<double>(), c->g_I.as<double>(),
-                       (double)n / c->s0, T * SC_TILE);
+                       c->g_z2.as<double>(), c->g_Inum.as<double>(), c->g_slag.as<double>(), c->g_mean.as<double>(),
+                       c->g_lat.as<double>(), c->g_seff.as<double>(), c->g_corr.as<double>(), c->g_thr.as<double>(),
+                       c->g_I.as<double>(), (double)n / c->s0, c->g_uniform_w, T * SC_TILE);
     SC_HIP(hipGetLastError());
     if (n_perm > 0) {
         // partial sums for one chunk of permutations (<= PERM_CHUNK): the persistent kernel keeps one row per
-        // (64-gene-padded gene, split, permutation); the fp64 kernel one per (16 genes, split, permutation)
+        // (128-gene-padded gene, split, permutation); the index-row kernel one per (16 genes, split, permutation)
         int64_t cps = 0;
-        const int splits64 = pick_splits(n, 1, &cps);  // upper bound on the fp64 kernel's split count
+        const int splits64 = pick_splits(n, 1, &cps);  // upper bound on the index-row kernel's split count
         const int64_t score_splits = ceil_div64(n, score_cells_per_split(n));
         const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
         const size_t wide_rows = (size_t)splits64 * SC_TILE;
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
-        if (!c->x32_valid) {
-            // the narrowest EXACT copy of the raw values the caller allows: uint16 (64 genes per 128-byte row) for
-            // count data, else float32 (32 genes per row), else none (fp64 tiles, 16 genes per row)
+        if (bits < 64) {
+            // the gathered operand: the raw values in the narrowest type that holds every gene of the batch exactly
             const int64_t T32 = (T + 1) / 2;
             SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= the uint16 / uint8 copies
-            SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
-            c->narrow_bits = 64;
-            for (int bits = 8; bits <= 32 && c->narrow_bits == 64; bits *= 2) {
-                if (bits < c->source_bits_min) continue;
-                SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
-                const int tg = bits == 8 ? 8 : bits == 16 ? 4 : 2;
-                const dim3 grid((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, tg));
-                auto pack = bits == 8 ? k_pack_narrow<8> : bits == 16 ? k_pack_narrow<16> : k_pack_narrow<32>;
-                hipLaunchKernelGGL(pack, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T,
-                                   c->perm_flag.as<int>());
-                int inexact = 0;
-                SC_HIP(hipMemcpyAsync(&inexact, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                SC_HIP(hipStreamSynchronize(c->stream));
-                if (!inexact) c->narrow_bits = bits;
-            }
-            c->x32_exact = c->narrow_bits < 64;
-            c->x32_valid = true;
-        }
-        if (c->x32_exact && c->narrow_bits == 8) {   // the uint8 kernel's correction term mean * sum(lag), per gene
-            const size_t gb = (size_t)align_up64(T, 8) * SC_TILE * sizeof(double);
-            SC_TRY(c->g_slag.ensure(2 * gb, &c->mem));
-            double *slag = c->g_slag.as<double>(), *corr = slag + align_up64(T, 8) * SC_TILE;
-            SC_TRY(colsum<OP_ID>(c, c->Lag.as<double>(), nullptr, slag, 1.0));
-            hipLaunchKernelGGL(k_mean_times, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
-                               c->g_mean.as<double>(), slag, corr, T * SC_TILE);
+            const int tg = bits == 8 ? 8 : bits == 16 ? 4 : 2;
+            const dim3 grid((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, tg));
+            auto pack = bits == 8 ? k_pack_narrow<8> : bits == 16 ? k_pack_narrow<16> : k_pack_narrow<32>;
+            hipLaunchKernelGGL(pack, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T);
             SC_HIP(hipGetLastError());
         }
     }
@@ -948,18 +1063,13 @@ int sc_perm_forward_ensure(sc_ctx *c)
     return SC_OK;
 }
 
-// Decide whether the half-traffic kernel may be used for the active table; a table uploaded by the
-// caller is only trusted after checking that every row is a bijection (inverse of the inverse).
-// narrowest exact source the scoring may gather: 32 (float32 raw values), 64 (the fp64 kernel)
-static int moran_source_bits(const sc_ctx *c)
+// The scoring kernels gather through the INVERSE rows, which exist only for true permutations: a table uploaded by
+// the caller is checked once (inverse of the inverse).  *bijective = false: its rows are arbitrary index maps and
+// take the index-row kernel (k_moran_perm).
+static int moran_table_is_bijective(sc_ctx *c, int64_t n_perm, bool *bijective)
 {
-    return c->x32_exact ? c->narrow_bits : 64;
-}
-
-static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
-{
-    *bits = 64;
-    if (n_perm <= 0 || moran_source_bits(c) == 64) return SC_OK;
+    *bijective = false;
+    if (n_perm <= 0) return SC_OK;
     const int64_t rows = c->p_count > n_perm ? c->p_count : n_perm;  // the WHOLE table is checked once
     SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * rows + 32), &c->mem));
     if (!c->perm_bijective && !c->perm_checked) {
@@ -975,25 +1085,35 @@ static int moran_choose_path(sc_ctx *c, int64_t n_perm, int *bits)
         c->perm_bijective = (bad == 0);
         if (c->perm_bijective) c->inv_rows_valid = rows;
     }
-    if (c->perm_bijective) *bits = moran_source_bits(c);
+    *bijective = c->perm_bijective;
     return SC_OK;
 }
 
+template <int BITS, int CB, bool BIG>
+static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int cnt, int64_t cps, int splits, int groups)
+{
+    hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
+                       c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
+                       c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
+                       splits, groups);
+}
+
 // score permutations [p0, p1) of the active table for every gene (on the context stream).
-// bits: 64 = fp64 kernel over the permutation rows; 16 / 32 = the persistent kernel gathers the narrow raw values
-// through the INVERSE permutation (needs inverse rows [p0, p1); invert_here launches that inversion first).
+// bits: 8 / 16 / 32 / 64 = the persistent kernel gathers rows of that element width through the INVERSE permutation
+// (needs inverse rows [p0, p1); invert_here launches that inversion first); 0 = the table's rows are arbitrary index
+// maps: the index-row kernel over the fp64 tiles.
 static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool invert_here)
 {
     const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
     const size_t tile_elems = (size_t)n * SC_TILE;
     const int cnt = (int)(p1 - p0);
     if (cnt <= 0) return SC_OK;
-    c->last_source_bits = bits;
-    if (bits <= 32) {
-        SC_REQUIRE(n < ((int64_t)1 << 25), SC_ERR_INVALID, "the narrow-source scoring kernel addresses rows with 32-bit "
-                   "byte offsets: n_cells must be < 2^25 (got %lld); use sc_ctx_set_moran_source_bits(ctx, 64)", (long long)n);
+    c->last_source_bits = bits ? bits : 64;
+    if (bits) {
+        const bool big = n >= ((int64_t)1 << 25);
+        SC_REQUIRE(!big || bits == 64, SC_ERR_STATE, "internal: %lld cells need the 64-bit-address scoring kernel", (long long)n);
         if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
-        const int GP = bits == 8 ? 128 : bits == 16 ? 64 : 32;
+        const int GP = bits == 8 ? 128 : bits == 16 ? 64 : bits == 32 ? 32 : 16;
         const int groups = (int)ceil_div64(T * SC_TILE, GP);
         const int64_t cps = score_cells_per_split(n);
         const int splits = (int)ceil_div64(n, cps);
@@ -1008,25 +1128,18 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         if ((int64_t)wgs * SCORE_WAVES > tasks) wgs = (int)ceil_div64(tasks, SCORE_WAVES);
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
-            // (8 cells per stage were measured too: under the 128-VGPR cap of the 1024-thread form they spill)
-            auto kern = bits == 8 ? k_moran_score<8, 4> : bits == 16 ? k_moran_score<16, 4> : k_moran_score<32, 4>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, c->X32.as<uint4>(),
-                               c->Lag.as<double>(), (int64_t)tile_elems, (int)T, c->g_mean.as<double>(),
-                               c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), n, c->p_stride, cnt, cps,
-                               splits, groups);
+            // (8 cells per stage were measured for the narrow sources too: under the 128-VGPR cap of the 1024-thread form they spill)
+            if (bits == 8) launch_score<8, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            else if (bits == 16) launch_score<16, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            else if (bits == 32) launch_score<32, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            else if (!big) launch_score<64, 8, false>(c, wgs, c->Z.as<uint4>(), p0, cnt, cps, splits, groups);
+            else launch_score<64, 8, true>(c, wgs, c->Z.as<uint4>(), p0, cnt, cps, splits, groups);
         }
         const dim3 fgrid((unsigned)ceil_div64((int64_t)cnt * GP, 256), (unsigned)groups);
-        const double *no_corr = nullptr;
-        if (bits == 8)
-            hipLaunchKernelGGL(k_moran_finalize_groups<128>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
-                               c->g_scale.as<double>(), c->g_slag.as<double>() + align_up64(T, 8) * SC_TILE,
-                               c->sims.as<double>(), cnt, splits, G, p0);
-        else if (bits == 16)
-            hipLaunchKernelGGL(k_moran_finalize_groups<64>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
-                               c->g_scale.as<double>(), no_corr, c->sims.as<double>(), cnt, splits, G, p0);
-        else
-            hipLaunchKernelGGL(k_moran_finalize_groups<32>, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(),
-                               c->g_scale.as<double>(), no_corr, c->sims.as<double>(), cnt, splits, G, p0);
+        auto fin = bits == 8 ? k_moran_finalize_groups<128> : bits == 16 ? k_moran_finalize_groups<64>
+                 : bits == 32 ? k_moran_finalize_groups<32> : k_moran_finalize_groups<16>;
+        hipLaunchKernelGGL(fin, fgrid, dim3(256), 0, c->stream, c->partial.as<double>(), c->g_seff.as<double>(),
+                           c->g_corr.as<double>(), c->sims.as<double>(), c->sims_raw.as<double>(), cnt, splits, G, p0);
         SC_HIP(hipGetLastError());
         return SC_OK;
     }
@@ -1042,10 +1155,18 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
                                cnt, cps);
         }
         hipLaunchKernelGGL(k_moran_finalize, dim3((unsigned)ceil_div64((int64_t)cnt * SC_TILE, 256)), dim3(256), 0,
-                           c->stream, c->partial.as<double>(), c->g_scale.as<double>() + t * SC_TILE,
-                           c->sims.as<double>(), cnt, splits, G, t * SC_TILE, p0);
+                           c->stream, c->partial.as<double>(), c->g_seff.as<double>(), c->g_corr.as<double>(),
+                           c->sims.as<double>(), c->sims_raw.as<double>(), cnt, splits, G, t * SC_TILE, p0);
     }
     SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+static int moran_alloc_sims(sc_ctx *c, int64_t n_perm)
+{
+    const size_t bytes = sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1);
+    SC_TRY(c->sims.ensure(bytes, &c->mem));
+    SC_TRY(c->sims_raw.ensure(bytes, &c->mem));
     return SC_OK;
 }
 
@@ -1058,7 +1179,8 @@ static int moran_finish(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
         SC_TRY(c->sim_sum.ensure(sizeof(double) * (size_t)G, &c->mem));
         SC_TRY(c->sim_sumsq.ensure(sizeof(double) * (size_t)G, &c->mem));
         hipLaunchKernelGGL(k_moran_count, dim3((unsigned)G), dim3(256), 0, c->stream, c->sims.as<double>(),
-                           c->g_I.as<double>(), (int)n_perm, G, c->counts.as<long long>(), c->sim_sum.as<double>(),
+                           c->sims_raw.as<double>(), c->g_thr.as<double>(), c->g_lat.as<double>(), c->g_z2.as<double>(),
+                           (int)n_perm, G, c->counts.as<long long>(), c->sim_sum.as<double>(),
                            c->sim_sumsq.as<double>());
         SC_HIP(hipGetLastError());
         if (sims_out)
@@ -1089,21 +1211,19 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
         SC_REQUIRE(c->p_n == c->e_n, SC_ERR_INVALID, "sc_moran: permutation length %lld != n_cells %lld",
                    (long long)c->p_n, (long long)c->e_n);
     }
-    SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
-    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1),
-                          &c->mem));
-    // A table left by sc_moran_seeded may exist only as inverse rows, which is all the float32-source kernel reads:
-    // the permutation rows themselves are materialised only when something needs them (the fp64 kernel, or rows
-    // whose inverse is not there yet).
-    const bool inverse_suffices = n_perm > 0 && c->perm_bijective && c->inv_rows_valid >= n_perm &&
-                                  moran_source_bits(c) <= 32;
+    // A table left by sc_moran_seeded may exist only as inverse rows, which is all the scoring kernel reads: the
+    // permutation rows themselves are materialised only when rows are needed whose inverse is not there yet.
+    const bool inverse_suffices = n_perm > 0 && c->perm_bijective && c->inv_rows_valid >= n_perm;
     if (n_perm > 0 && !inverse_suffices) SC_TRY(sc_perm_forward_ensure(c));
-    int bits = 64;
-    SC_TRY(moran_choose_path(c, n_perm, &bits));
+    bool bijective = true;
+    SC_TRY(moran_table_is_bijective(c, n_perm, &bijective));
+    SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK, n_perm <= 0 || bijective));
+    SC_TRY(moran_alloc_sims(c, n_perm));
+    const int bits = bijective ? c->narrow_bits : 0;
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) {
         const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
-        SC_TRY(moran_perm_range(c, p0, p1, bits, p1 > c->inv_rows_valid));
-        if (bits <= 32 && p1 > c->inv_rows_valid) c->inv_rows_valid = p1;
+        SC_TRY(moran_perm_range(c, p0, p1, bits, bits != 0 && p1 > c->inv_rows_valid));
+        if (bits != 0 && p1 > c->inv_rows_valid) c->inv_rows_valid = p1;
     }
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
@@ -1218,27 +1338,17 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     SC_TRY(moran_check(c, n_perm, I_out));
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "sc_moran_seeded: n_perm must be >= 1 (use sc_moran for n_perm = 0)");
     const int64_t n = c->e_n;
-    SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(c->e_tiles * SC_TILE) * (size_t)n_perm, &c->mem));
-    // a float32 matrix is its own exact float32 copy: the scoring will gather through the inverse table only (the
-    // inverse of a Fisher-Yates result is the same transpositions in ascending order: no table, no scatter pass)
-    const bool inverse_only = c->e_dtype == SC_F32 && c->source_bits_min <= 32 && permgen_can_swap_inverse(n);
+    SC_TRY(moran_alloc_sims(c, n_perm));
+    // every scoring kernel gathers through the inverse table only (the inverse of a Fisher-Yates result is the same
+    // transpositions in ascending order: no permutation rows, no scatter pass)
+    const bool inverse_only = permgen_can_swap_inverse(n);
     int bits = 64;
-    bool need_forward = false;
     auto prepare = [&]() -> int {
-        SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK));
-        bits = moran_source_bits(c);
-        // (a float32 matrix with NaNs fails the exactness test of its narrow copy: the fp64 kernel then needs the
-        // permutation rows themselves, made below from the inverse rows chunk by chunk)
-        need_forward = inverse_only && bits > 32;
+        SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK, true));
+        bits = c->narrow_bits;
         return SC_OK;
     };
     auto score = [&](int64_t p0, int64_t p1) -> int {
-        if (need_forward) {
-            const int rows = (int)(p1 - p0);
-            hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((rows + 7) / 8) * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0,
-                               c->stream, c->inv.as<int32_t>() + p0 * c->p_stride, c->perm.as<int32_t>() + p0 * c->p_stride,
-                               c->e_n, c->p_stride, rows);
-        }
         // The last chunk is scored after the generator has finished (its own swaps are the generator's last launches):
         // it takes the CUs the earlier launches left to the generator; the one before it runs beside the generator's
         // short last chunk only.  SC_SCORE_LEAVE_TAIL="a,b" (development): CUs left by the second-to-last / last
@@ -1255,7 +1365,6 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         return rc;
     };
     SC_TRY(sc_perm_pipeline(c, state6, n, n_perm, inverse_only ? 1 : 2, prepare, score));
-    if (need_forward) c->perm_forward_valid = true;
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 

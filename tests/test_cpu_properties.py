@@ -108,3 +108,43 @@ def test_padj_tables_match_per_gene_corrections():
             want = np.ones(n, dtype=np.float32)
             want[:] = fn(p[:, g])
             np.testing.assert_array_equal(tab[g][counts[:, g]], want, err_msg=f"{method} gene {g}")
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 2**31 - 1), st.integers(30, 120), st.integers(2, 6))
+def test_lattice_count_is_the_exact_arithmetic_count(seed, n, k):
+    """Integer counts on a kNN graph (all weights 1/k): the oracle's lattice count #{T_p >= T_obs}, T = sum_i x_i S[perm_i],
+    equals the count of `sims_p >= I` evaluated in EXACT rational arithmetic on the reference's definition
+    (z = x - mean, lag = W z, sum_i z_i lag[perm_i]); the float comparison agrees wherever no permutation ties."""
+    from fractions import Fraction
+
+    import oracle as orc
+    from scipy.sparse import csr_matrix
+
+    rng = np.random.default_rng(seed)
+    coords = rng.uniform(0, 100, (n, 2))
+    # two levels only for gene 0: many exact ties; gene 1 Poisson; gene 2 not a lattice gene (fractional values)
+    vals = np.stack([rng.integers(0, 2, n), rng.poisson(1.5, n), rng.poisson(1.5, n) + 0.5]).astype(np.float64)
+    idx = orc.knn_tree(coords, k)
+    g = orc.row_normalize_l1(csr_matrix((np.ones(n * k), idx.reshape(-1), np.arange(0, n * k + 1, k)), shape=(n, n)))
+    P = 40
+    perms, _ = orc.perm_table(seed % 1000, n, P)
+    count, lat = orc.morans_count_ge(g, vals, perms)
+    assert lat.tolist() == [True, True, False]
+    sims = orc.morans_i_sims_gather(g, vals, perms)
+    score = orc.morans_i_scores(g, vals)
+    for gi in (0, 1):
+        x = [Fraction(int(v)) for v in vals[gi]]
+        mean = sum(x) / n
+        z = [v - mean for v in x]
+        lag = [sum(z[j] for j in idx[i]) / k for i in range(n)]
+        obs = sum(z[i] * lag[i] for i in range(n))
+        exact = [sum(z[i] * lag[perms[p][i]] for i in range(n)) for p in range(P)]
+        want = sum(1 for v in exact if v >= obs) if any(v != x[0] for v in x) else 0
+        assert count[gi] == want
+        ties = sum(1 for v in exact if v == obs)
+        assert abs(int((sims[:, gi] >= score[gi]).sum()) - want) <= ties
+    assert count[2] == (sims[:, 2] >= score[2]).sum()
+    # a graph with unequal weights has no lattice genes
+    g2 = g.copy(); g2.data[0] *= 0.5
+    assert not orc.lattice_genes(g2, vals).any()
