@@ -198,6 +198,35 @@ int sc_timer_collect(sc_ctx *c);
 int sc_expr_zscores(sc_ctx *c);  // Z = (X - mean) / population sd per gene (0 for zero variance), variances in g_var
 int sc_lag_tiles(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const DBuf &data, const double *Z, double *out);
 
+// 64-bit masks and per-lane variable shifts built from 32-bit instructions whose shift amounts are IN RANGE by
+// construction.  r02 finding (ISA diff in r03): the one instruction that produced wrong values
+// next to kernels of other hardware queues was a v_lshlrev_b64 whose per-lane amount register held 0 - r (the compiler's
+// form of (64 - r) & 63, legal only through the instruction's implicit 6-bit masking of the amount); the right shift by
+// r itself, in the same kernel, never failed.  Device code therefore keeps per-lane 64-bit shifts out of the ISA: these
+// helpers compile to v_lshlrev_b32 / v_lshrrev_b32 / v_alignbit_b32 with amounts masked to [0, 31] in the source.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t sc_low_mask64(uint32_t d)   // the d low bits set, d in [0, 64]
+{
+    const uint32_t part = (1u << (d & 31u)) - 1u;
+    const uint32_t lo = d >= 32u ? 0xffffffffu : part;
+    const uint32_t hi = d >= 64u ? 0xffffffffu : (d > 32u ? part : 0u);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t sc_bit64(uint32_t pos)      // 1 << pos, pos in [0, 63]
+{
+    const uint32_t b = 1u << (pos & 31u);
+    const uint32_t lo = (pos & 32u) ? 0u : b, hi = (pos & 32u) ? b : 0u;
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t sc_shr64(uint64_t x, uint32_t pos)   // x >> pos, pos in [0, 63]
+{
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    if (pos & 32u) { xl = xh; xh = 0u; }
+    const uint32_t k = pos & 31u;
+    return ((uint64_t)(xh >> k) << 32) | __builtin_amdgcn_alignbit(xh, xl, k);
+}
+#endif
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }
 

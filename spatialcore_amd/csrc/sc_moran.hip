@@ -893,6 +893,193 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same scoring with the lag rows SHARED BY THE WORKGROUP (r03).
+//
+// What bounds k_moran_score (r03 measurement, bench size, all three narrow widths, alone and inside the pipeline): the
+// bytes a compute unit pulls through its vector memory path, ~35 GB/s per CU -- gathered rows AND lag rows alike.  There
+// every wavefront fetches the lag rows of its cells for itself: 1 KB of lag per 1 KB of gathered rows for the uint8
+// source (8 lag tiles per 128-gene row), i.e. HALF of a compute unit's traffic is the same lag rows arriving 16 times.
+// Here a task is (gene group, cell split, 128 permutations): the workgroup's 16 wavefronts score 8 permutations each
+// over the SAME cells, and the lag rows of a super-block of SB = 16 cells are loaded ONCE per workgroup -- every thread
+// one 16-byte piece, a single load instruction per wavefront and super-block -- into a double-buffered LDS tile
+// (2 x 16 cells x ROW pieces: 32 KB for uint8), handed over by ONE workgroup barrier per 16 cells.  Bytes through the
+// compute unit per gathered row: 128 + 4 + 128 TG / 16 instead of 128 + 4 + 128 TG.  Same products, same order of
+// summation per (gene, permutation): bit-identical to k_moran_score.
+// A super-block = 16 / CB stages of the software pipeline of k_moran_score (gather rows(b + 1), indices(b + 3), multiply
+// block b); its first stage also issues the lag load of the NEXT super-block, its last stage parks it in the other LDS
+// buffer and ends with the barrier.  The pipelined region has NO branch: hipcc's wait-count pass answers a divergent
+// path with s_waitcnt vmcnt(0), which would drain the gathers in flight (measured in the ISA of two earlier forms: a
+// loader-wavefront `if`, and a skip for wavefronts beyond the chunk's permutations).  Hence: narrower sources, whose 16
+// cells have fewer than 1024 pieces, load some pieces twice (same bytes to the same LDS address), and wavefronts beyond
+// the chunk's permutations score their clamped permutation again and drop the result -- the host sends chunks that would
+// idle more than a quarter of a task's wavefronts (the pipeline's short first / last chunk) to k_moran_score instead.
+// ------------------------------------------------------------------------------------------------
+#define SCORE_SB 16   // cells per lag super-block
+
+template <int BITS, int CB, bool BIG>
+__global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
+    const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
+    const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
+    int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
+{
+    static_assert((BITS == 8 || BITS == 16 || BITS == 32 || BITS == 64) && (CB == 4 || CB == 8), "source width / block size");
+    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : BITS == 32 ? 2 : 1;
+    constexpr bool CENTER = BITS == 16 || BITS == 32;
+    constexpr int ROW = TG * 8;
+    constexpr int NI = CB / 4;
+    constexpr int SPS = SCORE_SB / CB;            // pipeline stages per super-block
+    constexpr int PIECES = SCORE_SB * ROW;        // 16-byte pieces of one super-block's lag rows (<= 1024)
+    static_assert(PIECES <= SCORE_WAVES * 64 && (SCORE_WAVES * 64) % PIECES == 0, "every thread loads one piece");
+    __shared__ double2 lds_lag[2][PIECES];        // [buffer][cell][ROW]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane >> 3, q = lane & 7;
+    const int pid = (int)threadIdx.x % PIECES;    // this thread's piece of every super-block
+    const int lcell = pid / ROW, ltile = (pid % ROW) >> 3;
+    const int pchunks = (n_perm + 8 * SCORE_WAVES - 1) / (8 * SCORE_WAVES);
+    const int64_t n_tasks = (int64_t)n_groups * n_splits * pchunks;
+
+    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int pch = (int)(task % pchunks);
+        const int64_t rest = task / pchunks;
+        const int split = (int)(rest % n_splits), grp = (int)(rest / n_splits);
+        const int pbase = (pch * SCORE_WAVES + wave) * 8;
+        const bool live = pbase < n_perm;          // wavefront-uniform
+        const int p = pbase + r;
+        const int pc = p < n_perm ? p : n_perm - 1;
+        const int64_t c0 = (int64_t)split * cells_per_split;
+        int64_t c1 = c0 + cells_per_split;
+        if (c1 > n) c1 = n;
+        const int32_t *irow = inv + (int64_t)pc * pstride;
+        const char *Xg = reinterpret_cast<const char *>(narrow + (int64_t)grp * n * 8);
+        const uint32_t qoff = (uint32_t)q * 16u;
+        auto row_of = [&](int32_t i) {
+            if constexpr (BIG) return *reinterpret_cast<const uint4 *>(Xg + ((uint64_t)(uint32_t)i * 128u + qoff));
+            else return *reinterpret_cast<const uint4 *>(Xg + ((uint32_t)i * 128u + qoff));
+        };
+        const int tiles_left = tiles16 - TG * grp;
+        const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
+        // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
+        const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (pid & 7);
+        double m[CENTER ? TG : 1][2], acc[TG][2];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            if constexpr (CENTER) {
+                const double *mt = mean + (int64_t)(TG * grp + (t < tiles_left ? t : 0)) * SC_TILE + 2 * q;
+                m[t][0] = mt[0]; m[t][1] = mt[1];
+            }
+            acc[t][0] = acc[t][1] = 0.0;
+        }
+        const int64_t nsb = (c1 - c0) / SCORE_SB;   // whole super-blocks of the split (the rest: tail loop below)
+        const int64_t nblk = nsb * SPS;
+
+        double2 lg;
+        uint4 xa[CB], xb[CB];
+
+        auto load_idx = [&](int4 (&id)[NI], int64_t b) {
+            const int64_t bb = b < nblk ? b : nblk - 1;   // past the end: a harmless reload of the last block
+#pragma unroll
+            for (int k = 0; k < NI; ++k) id[k] = *reinterpret_cast<const int4 *>(irow + c0 + bb * CB + 4 * k);
+        };
+        auto load_lag = [&](int64_t sb) {
+            const int64_t ss = sb < nsb ? sb : nsb - 1;
+            lg = lsrc[(c0 + ss * SCORE_SB + lcell) * 8];
+        };
+        auto gather = [&](uint4 (&x)[CB], const int4 (&id)[NI]) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                x[4 * k + 0] = row_of(id[k].x);
+                x[4 * k + 1] = row_of(id[k].y);
+                x[4 * k + 2] = row_of(id[k].z);
+                x[4 * k + 3] = row_of(id[k].w);
+            }
+        };
+        auto mul_cell = [&](const uint4 &x, const double2 *lr) {
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const double2 l = lr[t * 8];
+                double v0, v1;
+                if (BITS == 8) {
+                    const uint32_t h = w[t >> 1] >> (16 * (t & 1));
+                    v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
+                } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                else if (BITS == 32) { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                else { v0 = __hiloint2double((int)w[1], (int)w[0]); v1 = __hiloint2double((int)w[3], (int)w[2]); }
+                if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
+                acc[t][0] = fma(l.x, v0, acc[t][0]);
+                acc[t][1] = fma(l.y, v1, acc[t][1]);
+            }
+        };
+        // one stage for block b = sb * SPS + k: `cur` holds its gathered rows; `nxt` receives block b + 1; `id_next` holds
+        // the indices of block b + 1 and is refilled with those of block b + 1 + SPS, i.e. every index vector is consumed in
+        // the NEXT trip of the super-block loop (consumed in the same trip, hipcc sinks the load down to its use -- seen in
+        // the IR -- and the gather then waits vmcnt(0) for it)
+        auto stage = [&](const uint4 (&cur)[CB], uint4 (&nxt)[CB], int4 (&id_next)[NI], int64_t sb, int k) {
+            if (k == 0) load_lag(sb + 1);            // (k is a literal at every call site)
+            __builtin_amdgcn_sched_barrier(0);       // issue order matters: vmcnt retires in order
+            gather(nxt, id_next);
+            __builtin_amdgcn_sched_barrier(0);
+            load_idx(id_next, sb * SPS + k + 1 + SPS);
+            __builtin_amdgcn_sched_barrier(0);
+            const double2 *lr = &lds_lag[sb & 1][k * CB * ROW + q];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) mul_cell(cur[c], lr + c * ROW);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == SPS - 1) {
+                lds_lag[(sb + 1) & 1][pid] = lg;     // (that buffer was last read in super-block sb - 1, before its barrier)
+                __syncthreads();
+            }
+        };
+
+        if (nsb > 0) {
+            int4 id0[NI], id1[NI], id2[NI], id3[NI];   // indices of blocks b + 1 .. b + SPS at the top of a trip (id0 .. id1 when SPS == 2)
+            load_lag(0);
+            load_idx(id3, 0);
+            gather(xa, id3);
+            load_idx(id0, 1);
+            load_idx(id1, 2);
+            if constexpr (SPS == 4) { load_idx(id2, 3); load_idx(id3, 4); }
+            lds_lag[0][pid] = lg;
+            __syncthreads();
+            for (int64_t sb = 0; sb < nsb; ++sb) {
+                stage(xa, xb, id0, sb, 0);
+                stage(xb, xa, id1, sb, 1);
+                if constexpr (SPS == 4) {
+                    stage(xa, xb, id2, sb, 2);
+                    stage(xb, xa, id3, sb, 3);
+                }
+            }
+        }
+        if (live) {
+            for (int64_t j = c0 + nsb * SCORE_SB; j < c1; ++j) {   // ragged tail of the split (< 16 cells): straight from global memory
+                const uint4 x = row_of(irow[j]);
+                const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const double2 l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
+                    double v0, v1;
+                    if (BITS == 8) {
+                        const uint32_t h = w[t >> 1] >> (16 * (t & 1));
+                        v0 = (double)(h & 0xffu); v1 = (double)((h >> 8) & 0xffu);
+                    } else if (BITS == 16) { v0 = (double)(w[t] & 0xffffu); v1 = (double)(w[t] >> 16); }
+                    else if (BITS == 32) { v0 = (double)__uint_as_float(w[2 * t]); v1 = (double)__uint_as_float(w[2 * t + 1]); }
+                    else { v0 = __hiloint2double((int)w[1], (int)w[0]); v1 = __hiloint2double((int)w[3], (int)w[2]); }
+                    if constexpr (CENTER) { v0 -= m[t][0]; v1 -= m[t][1]; }
+                    acc[t][0] = fma(l.x, v0, acc[t][0]);
+                    acc[t][1] = fma(l.y, v1, acc[t][1]);
+                }
+            }
+            if (p < n_perm) {
+                // partial[group][split][perm][16 t + 2 q + e]
+                double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)grp * n_splits + split) * n_perm + p) * ROW + q;
+#pragma unroll
+                for (int t = 0; t < TG; ++t) out[t * 8] = make_double2(acc[t][0], acc[t][1]);
+            }
+        }
+    }
+}
+
 // sims[p0 + p][GP grp + slot] = seff * (sum_s partial[grp][s][p][slot] - corr) (ascending s), raw = the sum itself, for
 // every gene group of a chunk in one launch (GP = genes per group: 128 / 64 / 32 / 16 by source width); seff, corr:
 // k_moran_scale
@@ -1092,6 +1279,19 @@ static int moran_table_is_bijective(sc_ctx *c, int64_t n_perm, bool *bijective)
 template <int BITS, int CB, bool BIG>
 static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int cnt, int64_t cps, int splits, int groups)
 {
+    static const bool private_lag = getenv("SC_SCORE_PRIVATE_LAG") != nullptr;   // development: the r02 form, for A/B runs
+    // the workgroup form scores 128 permutations per task; a chunk that would leave more than a quarter of the last
+    // task's wavefronts idle (the pipeline's short first and last chunks) takes the per-wavefront form -- same results
+    const int idle = (8 * SCORE_WAVES - cnt % (8 * SCORE_WAVES)) % (8 * SCORE_WAVES);
+    if (!private_lag && idle <= 2 * SCORE_WAVES) {
+        const int64_t tasks = (int64_t)groups * splits * ((cnt + 8 * SCORE_WAVES - 1) / (8 * SCORE_WAVES));
+        if (wgs > tasks) wgs = (int)tasks;
+        hipLaunchKernelGGL((k_moran_score_wg<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
+                           c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
+                           c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
+                           splits, groups);
+        return;
+    }
     hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
                        c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
                        c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
@@ -1669,7 +1869,8 @@ __global__ __launch_bounds__(256) void k_npc_scatter(const double *__restrict__ 
         for (int g = 0; g < 16; ++g) {
             const bool nz = v[g] != 0.0;
             const unsigned long long bal = __ballot(nz);
-            const uint32_t below = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            // set bits of the ballot below this lane: the hardware's own mask-below-lane count (no per-lane 64-bit shift)
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             if (nz) comp[(tile * 16 + g) * n + base[g] + below] = (T)v[g];
             base[g] += (uint32_t)__popcll(bal);
         }

@@ -521,7 +521,7 @@ __device__ __forceinline__ uint32_t select64(uint64_t x, uint32_t r)  // positio
     uint32_t pos = 0;
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {
-        const uint32_t c = (uint32_t)__popcll((x >> pos) & ((1ull << sh) - 1ull));
+        const uint32_t c = (uint32_t)__popcll(sc_shr64(x, pos) & ((1ull << sh) - 1ull));   // (sh is a literal: a constant mask)
         if (r >= c) { r -= c; pos += sh; }
     }
     return pos;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void phi_tbuild(const uint16_t *ev, uint32_t nev, uin
     uint64_t w0, w1, w2, w3;
     {
         const uint32_t base = 256 * lane;
-#define PHI_INIT(k) (w >= base + 64 * (k) + 64 ? ~0ull : (w > base + 64 * (k) ? ((1ull << (w - base - 64 * (k))) - 1ull) : 0ull))
+#define PHI_INIT(k) (w > base + 64 * (k) ? sc_low_mask64(w - base - 64 * (k) < 64u ? w - base - 64 * (k) : 64u) : 0ull)
         w0 = PHI_INIT(0); w1 = PHI_INIT(1); w2 = PHI_INIT(2); w3 = PHI_INIT(3);
 #undef PHI_INIT
     }
@@ -552,10 +552,10 @@ __device__ __forceinline__ void phi_tbuild(const uint16_t *ev, uint32_t nev, uin
             if (lane == L) {
                 uint32_t r = s - (pre - cnt);
                 const uint32_t c0 = (uint32_t)__popcll(w0), c1 = (uint32_t)__popcll(w1), c2 = (uint32_t)__popcll(w2);
-                if (r < c0) w0 &= ~(1ull << select64(w0, r));
-                else if (r < c0 + c1) w1 &= ~(1ull << select64(w1, r - c0));
-                else if (r < c0 + c1 + c2) w2 &= ~(1ull << select64(w2, r - c0 - c1));
-                else w3 &= ~(1ull << select64(w3, r - c0 - c1 - c2));
+                if (r < c0) w0 &= ~sc_bit64(select64(w0, r));
+                else if (r < c0 + c1) w1 &= ~sc_bit64(select64(w1, r - c0));
+                else if (r < c0 + c1 + c2) w2 &= ~sc_bit64(select64(w2, r - c0 - c1));
+                else w3 &= ~sc_bit64(select64(w3, r - c0 - c1 - c2));
                 cnt -= 1;
             }
             pre -= (lane >= L) ? 1u : 0u;
@@ -579,8 +579,7 @@ __device__ __forceinline__ uint32_t phi_lookup(const unsigned long long *tb, uin
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t lo = base + 64 * k;
-            if (idx >= lo + 64) t += (uint32_t)__popcll(wd[k]);
-            else if (idx > lo) t += (uint32_t)__popcll(wd[k] & ((1ull << (idx - lo)) - 1ull));
+            if (idx > lo) t += (uint32_t)__popcll(wd[k] & sc_low_mask64(idx - lo < 64u ? idx - lo : 64u));
         }
     }
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
@@ -708,9 +707,9 @@ __device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_
     uint32_t t = 0;
     if (idx > base) {
         const ulonglong2 a = tl[lane];
-        t = idx >= base + 64 ? (uint32_t)__popcll(a.x) : (uint32_t)__popcll(a.x & ((1ull << (idx - base)) - 1ull));
-        if (idx > base + 64)
-            t += idx >= base + 128 ? (uint32_t)__popcll(a.y) : (uint32_t)__popcll(a.y & ((1ull << (idx - base - 64)) - 1ull));
+        const uint32_t d = idx - base;   // >= 1
+        t = (uint32_t)__popcll(a.x & sc_low_mask64(d < 64u ? d : 64u));
+        if (d > 64u) t += (uint32_t)__popcll(a.y & sc_low_mask64(d - 64u < 64u ? d - 64u : 64u));
     }
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
 }

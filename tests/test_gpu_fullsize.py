@@ -276,3 +276,146 @@ def test_config4_shape_5m_cells_indexing():
         ctx.set_permutations(last[None, :])                       # the last row, scored from the host's table
         np.testing.assert_array_equal(ctx.moran(1)["sims"][0], one["sims"][P2 - 1])
         assert ctx.device_mem() < 120 * 2**30
+
+
+def _radius_graph_1m(ctx, coords):
+    """BASELINE configs[2] graph: closed-ball radius graph r = 30 um at 1M cells (~28 neighbours), float32-valued
+    1 / degree weights as the in-repo Lee path uses; returns the scipy matrix of the same values."""
+    from scipy.sparse import csr_matrix
+
+    indptr, indices = ctx.radius_graph(coords, 30.0)
+    deg = np.diff(indptr)
+    assert (deg > 0).all() and 20 < deg.mean() < 36
+    w = np.repeat((np.float32(1.0) / deg.astype(np.float32)).astype(np.float64), deg)
+    ctx.set_graph_csr(indptr, indices, w, N)
+    return csr_matrix((w, indices, indptr), shape=(N, N))
+
+
+def _zscores(X):
+    X = X.astype(np.float64)
+    return (X - X.mean(axis=0)) / X.std(axis=0)
+
+
+def test_config2_at_size_shared_permutation_grid_100x100(big, oracle):
+    """BASELINE configs[2] AT SIZE through the code it runs: 1M cells, radius graph r = 30 um, Lee's L for 100 x 100
+    gene pairs x 199 permutations with `shared_permutations` semantics (sc_lee_shared: k_lee_observed_mfma +
+    k_lee_shared_mfma).  One pair goes through the oracle's literal restatement of the reference's core loop
+    (oracle.lees_l_core: numpy's own rng.permutation + scipy mat-vec per permutation) over all 199 permutations; six
+    more pairs through the definition on three rows of the HOST generator's table; the grid's counts are those of its
+    own L_perm; the generator ends in numpy's state."""
+    from spatialcore_amd import _lib
+
+    ctx, coords, _ = big
+    W = _radius_graph_1m(ctx, coords)
+    rng = np.random.default_rng(21)
+    G, P, seed = 200, 199, 5
+    X = rng.poisson(rng.uniform(0.2, 3.0, G), (N, G)).astype(np.float32)
+    X[:, 100:130] += X[:, 0:30]                                  # some truly associated pairs among the independent ones
+    ctx.set_expression(X, np.arange(G))
+    gx, gy = np.arange(100), np.arange(100, 200)
+    w = _lib.rng_state_words(np.random.default_rng(seed))
+    out = ctx.lee_shared(w, gx, gy, P, return_perms=True)
+    wh = _lib.rng_state_words(np.random.default_rng(seed))
+    host = _lib.perm_numpy_host(wh, N, P)
+    np.testing.assert_array_equal(w, wh)                         # generator state after 199 x 1M Fisher-Yates steps
+    L, Lp, cnt = out["L"], out["L_perm"], out["count_abs_ge"]
+    assert L.shape == (100, 100) and Lp.shape == (P, 100, 100)
+    np.testing.assert_array_equal(cnt, (np.abs(Lp) >= np.abs(L)[None]).sum(axis=0))
+    assert (cnt[np.arange(30), np.arange(30)] == 0).all()        # the associated pairs (x_i, y_i): nothing reaches L
+    assert 0.3 < (cnt[40:, 40:] / P).mean() < 0.7                # independent pairs: |L_perm| >= |L| about half the time
+    Z = _zscores(X[:, [0, 3, 17, 42, 99, 100, 103, 117, 160, 199]])
+    zcol = {g: Z[:, i] for i, g in enumerate([0, 3, 17, 42, 99, 100, 103, 117, 160, 199])}
+    # (1) the reference's own loop, restated literally, for one pair over all permutations
+    _, L_ref, _, p_ref, Lp_ref = oracle.lees_l_core(zcol[3], zcol[103], W, P, np.random.default_rng(seed))
+    assert L[3, 3] == pytest.approx(L_ref, rel=1e-9)
+    np.testing.assert_allclose(Lp[:, 3, 3], Lp_ref, rtol=1e-9, atol=1e-7)
+    assert (cnt[3, 3] + 1) / (P + 1) == p_ref
+    # (2) the definition on the host generator's rows for other pairs: L_perm = sum_i zx_i (W zy[perm])_i
+    for a, b in [(0, 100), (17, 117), (42, 160), (99, 199), (0, 199), (42, 103)]:
+        assert L[a, b - 100] == pytest.approx(float(zcol[a] @ (W @ zcol[b])), rel=1e-9, abs=1e-6)
+        for p in (0, 57, P - 1):
+            want = float(zcol[a] @ (W @ zcol[b][host[p]]))
+            assert Lp[p, a, b - 100] == pytest.approx(want, rel=1e-9, abs=1e-6)
+
+
+def test_config2_at_size_per_pair_permutations_lee_seeded(big, oracle):
+    """The reference's semantics at size (AC:1109-1148: a fresh block of P permutations per pair from ONE stream):
+    sc_lee_seeded for 24 pairs x 199 permutations at 1M cells on the radius graph -- k_lee_observed_mfma + pipelined
+    k_lee_rows -- against (a) the per-pair path (sc_perm_generate of all 24 x 199 rows + sc_lee) on the same stream:
+    same counts, same statistics to summation order, same generator state; (b) the oracle's literal loop for the first
+    pair (it owns the first block of the stream)."""
+    from spatialcore_amd import _lib
+
+    ctx, coords, _ = big
+    W = _radius_graph_1m(ctx, coords)
+    rng = np.random.default_rng(22)
+    G, P, seed = 12, 199, 9
+    X = rng.poisson(rng.uniform(0.2, 3.0, G), (N, G)).astype(np.float32)
+    X[:, 7] = 2.0                                                # a zero-variance gene: its pairs draw nothing
+    ctx.set_expression(X, np.arange(G))
+    pairs = np.array([(a, b) for a in range(4) for b in range(4, 10)])       # 24 pairs, 4 of them with gene 7
+    live = (pairs != 7).all(axis=1)
+    w = _lib.rng_state_words(np.random.default_rng(seed))
+    before = ctx.permgen_stats()
+    out = ctx.lee_seeded(w, pairs[:, 0], pairs[:, 1], P, return_perms=True)
+    assert ctx.permgen_stats()[2] == before[2]                   # no verification fallback
+    w2 = _lib.rng_state_words(np.random.default_rng(seed))
+    ctx.generate_permutations(w2, N, int(live.sum()) * P)
+    np.testing.assert_array_equal(w, w2)
+    off = np.where(live, np.cumsum(live) - 1, -1) * P
+    off[~live] = -1
+    ref = ctx.lee(pairs[:, 0], pairs[:, 1], off, P, return_perms=True)
+    np.testing.assert_allclose(out["L"], ref["L"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(out["L_perm"][live], ref["L_perm"][live], rtol=1e-9, atol=1e-7)
+    np.testing.assert_array_equal(out["count_abs_ge"][live], ref["count_abs_ge"][live])
+    np.testing.assert_array_equal(out["count_abs_ge"][~live], P)
+    Z = _zscores(X[:, [0, 4]])
+    _, L_ref, _, p_ref, Lp_ref = oracle.lees_l_core(Z[:, 0], Z[:, 1], W, P, np.random.default_rng(seed))
+    assert out["L"][0] == pytest.approx(L_ref, rel=1e-9)
+    np.testing.assert_allclose(out["L_perm"][0], Lp_ref, rtol=1e-9, atol=1e-7)
+    assert (out["count_abs_ge"][0] + 1) / (P + 1) == p_ref
+
+
+def test_config4_at_size_enrichment_k30(big, oracle):
+    """BASELINE configs[4] AT SIZE through k_enrich: 1M cells, k = 30 neighbour graph, 20 cell types, 600 label
+    permutations through the public neighborhood_enrichment (two generator batches), and the raw T x T count tables
+    of the observed labels and of three sampled permutations against the oracle's restatement on the host generator's
+    rows (exact integers)."""
+    from scipy.spatial import cKDTree
+
+    from conftest import make_adata
+    from spatialcore_amd import _lib
+    from spatialcore_amd.spatial import neighborhood_enrichment
+
+    ctx, coords, _ = big
+    T, P, k, seed = 20, 600, 30, 13
+    codes = np.random.default_rng(3).choice(T, N, p=np.random.default_rng(4).dirichlet(np.ones(T))).astype(np.int32)
+    nbr = ctx.knn(coords, k)
+    ctx.graph_from_knn(1.0)
+    rows = np.random.default_rng(5).choice(N, 1000, replace=False)
+    _, nb = cKDTree(coords).query(coords[rows], k=k + 1)
+    np.testing.assert_array_equal(nbr[rows], nb[:, 1:])
+    w = _lib.rng_state_words(np.random.default_rng(seed))
+    ctx.generate_permutations(w, N, 512)
+    cnt = ctx.enrichment_counts(codes, T, 512)
+    wh = _lib.rng_state_words(np.random.default_rng(seed))
+    host = _lib.perm_numpy_host(wh, N, 512)
+    np.testing.assert_array_equal(w, wh)
+    assert cnt.shape == (513, T, T) and (cnt.sum(axis=(1, 2)) == N * k).all()
+    indptr = np.arange(0, N * k + 1, k, dtype=np.int64)
+    picks = [0, 255, 511]
+    want = oracle.enrichment_counts(indptr, np.sort(nbr, axis=1).reshape(-1), codes, T, host[picks])
+    np.testing.assert_array_equal(cnt[picks], want[:3])
+    np.testing.assert_array_equal(cnt[512], want[3])             # observed labels
+    # the public function (its own graph build, 512 + 88 permutations from one stream)
+    labels = np.array([f"type{c:02d}" for c in range(T)])[codes]
+    ad = make_adata(coords, np.zeros((N, 1), dtype=np.float32), labels=labels)
+    neighborhood_enrichment(ad, "cell_type", k=k, n_permutations=P, seed=seed)
+    res = ad.uns["neighborhood_enrichment"]
+    np.testing.assert_array_equal(res["count"], want[3])
+    assert res["p_value"].shape == (T, T) and res["p_value"].min() >= 1 / (P + 1) and res["p_value"].max() <= 1.0
+    first = (cnt[:512] >= cnt[512]).sum(axis=0)                  # the first batch's share of the exceedance counts
+    ge = np.rint(res["p_value"] * (P + 1) - 1).astype(np.int64)
+    assert (ge >= first).all() and (ge <= first + (P - 512)).all()
+    with np.errstate(invalid="ignore"):
+        assert np.nanmax(np.abs(res["zscore"])) < 8              # labels are independent of position: no enrichment
