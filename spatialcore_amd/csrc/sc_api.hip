@@ -156,7 +156,7 @@ int sc_ctx_destroy(sc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,
-                    &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->rad_indptr,
+                    &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->knn_hd, &c->knn_hi, &c->rad_indptr,
                     &c->g_indptr, &c->g_indices, &c->g_data, &c->gt_indptr, &c->gt_indices,
                     &c->gt_data, &c->gt_cursor, &c->X, &c->Z, &c->Lag, &c->X32, &c->inv, &c->e_tmp_indptr,
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,

@@ -232,6 +232,105 @@ __global__ __launch_bounds__(256) void k_knn(const double *__restrict__ sx, cons
         }
 }
 
+// k > 32 (any k < n): the k best candidates of a query live in a binary MAX-heap in global memory (slot j of query t
+// at [j * n + t]: the root, every thread's hottest slot, is a coalesced row), keyed by (squared distance, index); a
+// candidate that beats the root replaces it and sifts down.  The ring walk, the tie rule and the stopping rule are
+// those of k_knn; at the end the heap is sorted in place (heap sort) and scattered to the query's row.  The register
+// form needs 3 K registers per lane: K = 64 spilled 130 of them (r02) -- 33 <= k <= 64 come here too.
+__device__ __forceinline__ bool cand_worse(double d, int id, double ed, int eid) { return cand_better(ed, eid, d, id); }
+
+__device__ __forceinline__ void heap_sift_down(double *__restrict__ hd, int32_t *__restrict__ hi, int64_t n, int64_t t,
+                                               int size, double cd, int cid)
+{
+    // place (cd, cid) into the heap of `size` slots starting at the root, whose old content is dropped
+    int pos = 0;
+    for (;;) {
+        const int l = 2 * pos + 1, r = l + 1;
+        if (l >= size) break;
+        double wd = hd[(int64_t)l * n + t];
+        int wi = hi[(int64_t)l * n + t], w = l;
+        if (r < size) {
+            const double rd = hd[(int64_t)r * n + t];
+            const int ri = hi[(int64_t)r * n + t];
+            if (cand_worse(rd, ri, wd, wi)) { wd = rd; wi = ri; w = r; }
+        }
+        if (!cand_worse(wd, wi, cd, cid)) break;     // the candidate is at least as bad as both children: it stays here
+        hd[(int64_t)pos * n + t] = wd;
+        hi[(int64_t)pos * n + t] = wi;
+        pos = w;
+    }
+    hd[(int64_t)pos * n + t] = cd;
+    hi[(int64_t)pos * n + t] = cid;
+}
+
+__global__ __launch_bounds__(256) void k_knn_heap(const double *__restrict__ sx, const double *__restrict__ sy,
+                                                  const int32_t *__restrict__ sid,
+                                                  const int32_t *__restrict__ bin_start, int64_t n, int k,
+                                                  int include_self, double x0, double y0, double h, int nbx, int nby,
+                                                  double *__restrict__ hd, int32_t *__restrict__ hi,
+                                                  int32_t *__restrict__ idx_out, double *__restrict__ rd_out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double qx = sx[t], qy = sy[t];
+    const int qid = sid[t];
+    const double inv_h = 1.0 / h;
+    const int bx = bin_coord(qx, x0, inv_h, nbx), by = bin_coord(qy, y0, inv_h, nby);
+    for (int j = 0; j < k; ++j) { hd[(int64_t)j * n + t] = DBL_MAX; hi[(int64_t)j * n + t] = 0x7fffffff; }   // a valid heap
+    double root_d = DBL_MAX;
+    int root_i = 0x7fffffff;
+    const int rmax = (nbx > nby ? nbx : nby);
+    const double slack = 1e-9 * h;
+    for (int r = 0; r <= rmax; ++r) {
+        const int ylo = by - r, yhi = by + r, xlo = bx - r, xhi = bx + r;
+        const int cxlo = xlo < 0 ? 0 : xlo, cxhi = xhi >= nbx ? nbx - 1 : xhi;
+        for (int yy = (ylo < 0 ? 0 : ylo); yy <= (yhi >= nby ? nby - 1 : yhi); ++yy) {
+            const bool full = (yy == ylo) || (yy == yhi);
+            for (int seg = 0; seg < (full ? 1 : 2); ++seg) {
+                int b0, b1;
+                if (full) { b0 = cxlo; b1 = cxhi; }
+                else if (seg == 0) { if (xlo < 0) continue; b0 = b1 = xlo; }
+                else { if (xhi >= nbx || r == 0) continue; b0 = b1 = xhi; }
+                const int s0 = bin_start[yy * nbx + b0], s1 = bin_start[yy * nbx + b1 + 1];
+                for (int s = s0; s < s1; ++s) {
+                    const int cid = sid[s];
+                    const double dx = qx - sx[s], dy = qy - sy[s];
+                    const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                    if (cid == qid && !include_self) continue;
+                    if (cand_better(d, cid, root_d, root_i)) {
+                        heap_sift_down(hd, hi, n, t, k, d, cid);
+                        root_d = hd[t];
+                        root_i = hi[t];
+                    }
+                }
+            }
+        }
+        const bool l_out = xlo <= 0, r_out = xhi >= nbx - 1, b_out = ylo <= 0, t_out = yhi >= nby - 1;
+        if (l_out && r_out && b_out && t_out) break;  // everything visited
+        double m = DBL_MAX;
+        if (!l_out) m = fmin(m, qx - (x0 + (double)xlo * h));
+        if (!r_out) m = fmin(m, (x0 + (double)(xhi + 1) * h) - qx);
+        if (!b_out) m = fmin(m, qy - (y0 + (double)ylo * h));
+        if (!t_out) m = fmin(m, (y0 + (double)(yhi + 1) * h) - qy);
+        m -= slack;
+        if (m > 0.0 && root_d < m * m) break;        // the root is the k-th best so far
+    }
+    // heap sort: the worst of the remaining heap goes to its end; slots end up ascending by (distance, index)
+    for (int m = k - 1; m >= 1; --m) {
+        const double ld = hd[(int64_t)m * n + t];
+        const int li = hi[(int64_t)m * n + t];
+        hd[(int64_t)m * n + t] = hd[t];
+        hi[(int64_t)m * n + t] = hi[t];
+        heap_sift_down(hd, hi, n, t, m, ld, li);
+    }
+    int32_t *o = idx_out + (int64_t)qid * k;
+    double *od = rd_out ? rd_out + (int64_t)qid * k : nullptr;
+    for (int j = 0; j < k; ++j) {
+        o[j] = hi[(int64_t)j * n + t];
+        if (od) od[j] = hd[(int64_t)j * n + t];
+    }
+}
+
 template <int K>
 static void launch_knn(sc_ctx *c, int64_t n, int k, int include_self)
 {
@@ -244,7 +343,7 @@ extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int incl
                          double *rdist_out)
 {
     SC_REQUIRE(c && xy, SC_ERR_INVALID, "sc_knn_2d: null pointer");
-    SC_REQUIRE(k >= 1 && k <= 64, SC_ERR_INVALID, "sc_knn_2d: k=%d unsupported (1..64)", k);
+    SC_REQUIRE(k >= 1 && k <= (1 << 16), SC_ERR_INVALID, "sc_knn_2d: k=%d unsupported (1..65536)", k);
     SC_REQUIRE(n >= 1, SC_ERR_INVALID, "sc_knn_2d: n must be >= 1");
     SC_REQUIRE((int64_t)k <= n - (include_self ? 0 : 1), SC_ERR_INVALID,
                "sc_knn_2d: k=%d needs more than the %lld available points", k, (long long)n);
@@ -258,7 +357,14 @@ extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int incl
         if (k <= 8) launch_knn<8>(c, n, k, include_self);
         else if (k <= 16) launch_knn<16>(c, n, k, include_self);
         else if (k <= 32) launch_knn<32>(c, n, k, include_self);
-        else launch_knn<64>(c, n, k, include_self);
+        else {
+            SC_TRY(c->knn_hd.ensure(sizeof(double) * (size_t)n * k, &c->mem));
+            SC_TRY(c->knn_hi.ensure(sizeof(int32_t) * (size_t)n * k, &c->mem));
+            hipLaunchKernelGGL(k_knn_heap, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->sx.as<double>(),
+                               c->sy.as<double>(), c->sid.as<int32_t>(), c->bin_start.as<int32_t>(), n, k, include_self,
+                               c->gx0, c->gy0, c->gh, c->nbx, c->nby, c->knn_hd.as<double>(), c->knn_hi.as<int32_t>(),
+                               c->knn_idx.as<int32_t>(), c->knn_rd.as<double>());
+        }
     }
     SC_HIP(hipGetLastError());
     if (idx_out)

@@ -9,9 +9,9 @@ no CPU fallback -- without the shared library or a gfx950 device the functions r
 Extra keywords (keyword-only, defaults preserve reference behaviour): ``device`` = GPU ordinal; ``radius`` on
 ``morans_i`` / ``lees_l`` (closed-ball radius graph instead of kNN).
 
-Limits of the device path that the reference does not have: 2-D coordinates only; ``n_neighbors <= 64`` (63 with
-``include_self``): the neighbour search keeps a cell's k best candidates in registers (``ValueError`` beyond that);
-``n_cells < 2**25`` for the narrow-source permutation kernels (use ``sc_ctx_set_moran_source_bits(ctx, 64)`` above).
+Limit of the device path that the reference does not have: 2-D coordinates only (``ValueError`` otherwise; BASELINE's
+north_star is 2-D).  ``n_neighbors`` is unlimited (k <= 32: register top-k; above: per-cell heaps in device memory), and
+so is ``n_cells`` up to 2**31 - 1 (from 2**25 cells the permutation kernel gathers fp64 rows with 64-bit addresses).
 """
 
 from __future__ import annotations

@@ -310,7 +310,9 @@ def test_config2_at_size_shared_permutation_grid_100x100(big, oracle):
     rng = np.random.default_rng(21)
     G, P, seed = 200, 199, 5
     X = rng.poisson(rng.uniform(0.2, 3.0, G), (N, G)).astype(np.float32)
-    X[:, 100:130] += X[:, 0:30]                                  # some truly associated pairs among the independent ones
+    smooth = (2.0 * (1 + np.sin(coords[:, 0] / 900.0))).astype(np.float32)
+    X[:, 0:30] += smooth[:, None]                                # genes 0..29 and 100..129 share a spatially smooth part:
+    X[:, 100:130] += smooth[:, None]                             # truly associated pairs among the independent ones
     ctx.set_expression(X, np.arange(G))
     gx, gy = np.arange(100), np.arange(100, 200)
     w = _lib.rng_state_words(np.random.default_rng(seed))
@@ -321,7 +323,7 @@ def test_config2_at_size_shared_permutation_grid_100x100(big, oracle):
     L, Lp, cnt = out["L"], out["L_perm"], out["count_abs_ge"]
     assert L.shape == (100, 100) and Lp.shape == (P, 100, 100)
     np.testing.assert_array_equal(cnt, (np.abs(Lp) >= np.abs(L)[None]).sum(axis=0))
-    assert (cnt[np.arange(30), np.arange(30)] == 0).all()        # the associated pairs (x_i, y_i): nothing reaches L
+    assert (cnt[:30, :30] == 0).all() and (L[:30, :30] > 1e4).all()   # the associated pairs: no permutation reaches L
     assert 0.3 < (cnt[40:, 40:] / P).mean() < 0.7                # independent pairs: |L_perm| >= |L| about half the time
     Z = _zscores(X[:, [0, 3, 17, 42, 99, 100, 103, 117, 160, 199]])
     zcol = {g: Z[:, i] for i, g in enumerate([0, 3, 17, 42, 99, 100, 103, 117, 160, 199])}

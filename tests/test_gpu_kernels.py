@@ -39,7 +39,8 @@ def test_library_reports_native_path():
     assert _lib.device_count() >= 1
 
 
-@pytest.mark.parametrize("n,k", [(2000, 6), (5000, 15), (3000, 30), (400, 1), (700, 64), (50, 49)])
+@pytest.mark.parametrize("n,k", [(2000, 6), (5000, 15), (3000, 30), (400, 1), (700, 64), (50, 49), (3000, 33), (2500, 100),
+                                 (1500, 257), (300, 299)])   # k > 32: the global-memory heap form, any k < n
 def test_knn_bit_exact(ctx, oracle, n, k):
     rng = np.random.default_rng(n + k)
     xy = rng.uniform(0, np.sqrt(n) * 10, (n, 2))
