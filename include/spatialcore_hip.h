@@ -66,11 +66,13 @@ int sc_ctx_device_mem(sc_ctx *ctx, int64_t *bytes_in_use);
 int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64_t bytes);
 /* The permutation kernels of sc_moran / sc_moran_seeded gather the narrowest EXACT copy of the raw expression values,
  * one 128-byte row per cell and gene group: uint8 when every value is an integer count in [0, 255] (128 genes per
- * row), uint16 for counts up to 65535 (64 genes), else float32 when every value is a float32 (32 genes), else the fp64
- * tiles (16 genes).  The uint16 / float32 kernels rebuild z = (double)x - mean in registers (same z, same sums as the
- * fp64 tiles up to summation order); the uint8 kernel sums lag * x and subtracts mean * sum(lag) once per statistic.
+ * row; only when every loaded gene is a lattice gene, below), uint16 for counts up to 65535 (64 genes), else float32
+ * when every value is a float32 (32 genes), else the fp64 rows of the centred tiles (16 genes).  Every width rebuilds
+ * the same operands and adds the same products in the same order: a gene's statistics do not depend on the width, i.e.
+ * not on the genes it is loaded with.  Lattice genes (integer counts on a graph whose weights are all equal, e.g. kNN):
+ * scored as the exact integer sum_j S_j x[inv_p(j)] (S = unweighted neighbour sums), #{sims >= I} decided on integers.
  * min_bits (8, 16, 32 or 64; default 8) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
- * scoring call used (64 = the general fp64 kernel). */
+ * scoring call gathered. */
 int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
 int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
 /* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream
@@ -78,6 +80,12 @@ int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
  * device, sequential scan otherwise or when the verification fails), 1 = sequential scan only,
  * 2 = inject a fault into the block-parallel scan (exercises the verification + fallback; tests only). */
 int sc_ctx_set_permgen_mode(sc_ctx *ctx, int mode);
+/* Why the generator is not using its block-parallel form, "" when it is.  The form orders its kernels through words in
+ * device memory and needs its streams on different hardware queues (the library asks for GPU_MAX_HW_QUEUES=16 when it is
+ * loaded before the HIP runtime initialises -- a host application that initialised HIP first keeps its own setting);
+ * the context probes that once (5 rounds of 5-ms waits at worst), falls back to the sequential scan with identical
+ * results, and leaves the reason here.  sc_ctx_set_permgen_mode re-arms the probe. */
+int sc_ctx_permgen_note(sc_ctx *ctx, const char **message);
 /* Completed generator jobs by scan form, how often the block-parallel form failed its verification and the
  * job was rerun sequentially (0 unless mode 2 injected a fault), and for the block-parallel jobs (failed ones
  * included) the 16384-draw blocks resolved by a prepared table lookup / computed by the chain workgroup itself. */
@@ -138,6 +146,14 @@ int sc_expr_stats(sc_ctx *ctx, double *mean_out, double *var_out);
 int sc_perm_numpy_host(uint64_t *state6, int64_t n, int64_t n_perm, int32_t *perm_out);
 int sc_perm_generate(sc_ctx *ctx, uint64_t *state6, int64_t n, int64_t n_perm, int32_t *perm_out);
 int sc_perm_set(sc_ctx *ctx, const int32_t *perm, int64_t n, int64_t n_perm);
+/* EXTENSION (SURVEY 8(e) "alternative", H2) for the paths WITHOUT reference seed semantics (label-permutation
+ * enrichment, shared-permutation Lee grids; the reference has neither: NB:48-296, AC:1109-1148): counter-based
+ * permutations.  Permutation p is a pure function of (seed, p) -- Fisher-Yates with j = Lemire-bounded(Philox4x32-10(key =
+ * seed words, counter = (i, retry, p))) -- so ranks / batches take disjoint ranges [p_first, p_first + n_perm) and merge
+ * integer counts (sc_allreduce_sum_i64).  sc_perm_generate_counter makes them the resident table (rows 0 .. n_perm-1);
+ * sc_perm_counter_host is the same definition on the host (no GPU). */
+int sc_perm_generate_counter(sc_ctx *ctx, uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, int32_t *perm_out);
+int sc_perm_counter_host(uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, int32_t *perm_out);
 
 /* ---- A3 + A5 + A6 + A7: global Moran's I --------------------------------------------------
  * Replaces sq.gr.spatial_autocorr(mode="moran", n_perms=P, seed=seed) (AC:576-583):

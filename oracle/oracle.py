@@ -156,6 +156,53 @@ def raw_uint32(words: np.ndarray, count: int) -> np.ndarray:
     return out
 
 
+def philox4x32_10(counter: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123):
+    counter (..., 4) uint32 -> (..., 4) uint32.  Pinned by Random123's published known answers (tests)."""
+    c = np.array(counter, dtype=np.uint64).reshape(-1, 4).T.copy()
+    k0, k1 = np.uint64(key[0] & 0xFFFFFFFF), np.uint64(key[1] & 0xFFFFFFFF)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32
+        c = np.stack([n0, p1 & m32, n2, p0 & m32])
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.T.astype(np.uint32).reshape(np.shape(counter))
+
+
+def counter_permutation(seed: int, n: int, p: int) -> np.ndarray:
+    """EXTENSION (no reference semantics; defined in include/spatialcore_hip.h, sc_perm_generate_counter): permutation
+    p of the counter-based source -- Fisher-Yates as numpy runs it (i = n-1 .. 1: swap a[i], a[j]) with
+    j = Lemire-bounded(u, i + 1), u = first two words of Philox4x32-10(key = seed words, counter = (i, retry, p lo, p hi))."""
+    a = np.arange(n, dtype=np.int32)
+    if n < 2:
+        return a
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    i = np.arange(n - 1, 0, -1, dtype=np.uint64)
+    ctr = np.stack([i, np.zeros_like(i), np.full_like(i, p & 0xFFFFFFFF), np.full_like(i, (p >> 32) & 0xFFFFFFFF)], axis=1)
+    out = philox4x32_10(ctr.astype(np.uint32), key)
+    J = np.empty(n - 1, dtype=np.int64)
+    for s in range(n - 1):                                   # python integers: the 128-bit product of Lemire's method
+        rng_ = int(i[s]) + 1
+        u, r = (int(out[s, 1]) << 32) | int(out[s, 0]), 0
+        while True:
+            m = u * rng_
+            low = m & 0xFFFFFFFFFFFFFFFF
+            if low >= rng_ or low >= ((1 << 64) - rng_) % rng_:
+                break
+            r += 1
+            o = philox4x32_10(np.array([[int(i[s]), r, p & 0xFFFFFFFF, (p >> 32) & 0xFFFFFFFF]], dtype=np.uint32), key)[0]
+            u = (int(o[1]) << 32) | int(o[0])
+        J[s] = m >> 64
+    for s in range(n - 1):
+        ii, j = n - 1 - s, J[s]
+        a[ii], a[j] = a[j], a[ii]
+    return a
+
+
 # =============================================================================================
 # A1 / A2 -- neighbour search
 # =============================================================================================

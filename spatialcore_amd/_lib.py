@@ -33,6 +33,7 @@ SYMBOLS = {
     "sc_ctx_reset_timers": [_P],
     "sc_ctx_set_timing": [_P, c_int],
     "sc_ctx_set_permgen_mode": [_P, c_int],
+    "sc_ctx_permgen_note": [_P, POINTER(c_char_p)],
     "sc_ctx_set_moran_source_bits": [_P, c_int],
     "sc_ctx_moran_source_bits": [_P, _P],
     "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
@@ -52,6 +53,8 @@ SYMBOLS = {
     "sc_perm_numpy_host": [_P, c_int64, c_int64, _P],
     "sc_perm_generate": [_P, _P, c_int64, c_int64, _P],
     "sc_perm_set": [_P, _P, c_int64, c_int64],
+    "sc_perm_generate_counter": [_P, ctypes.c_uint64, c_int64, c_int64, c_int64, _P],
+    "sc_perm_counter_host": [ctypes.c_uint64, c_int64, c_int64, c_int64, _P],
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
@@ -168,6 +171,14 @@ def perm_numpy_host(words: np.ndarray, n: int, n_perm: int) -> np.ndarray:
     return out
 
 
+def perm_counter_host(seed: int, n: int, n_perm: int, p_first: int = 0) -> np.ndarray:
+    """Host-only counter-based permutations p_first .. p_first + n_perm - 1 (no GPU needed); see
+    Context.generate_permutations_counter."""
+    out = np.empty((n_perm, n), dtype=np.int32)
+    _check(load_library().sc_perm_counter_host(int(seed) & 0xFFFFFFFFFFFFFFFF, n, int(p_first), n_perm, _ptr(out)))
+    return out
+
+
 class Context:
     """One GPU + one HIP stream + the device-resident operands of the hot path."""
 
@@ -232,6 +243,18 @@ class Context:
         v = [c_int64(0) for _ in range(5)]
         _check(self._lib.sc_ctx_permgen_stats(self._h, *[byref(x) for x in v]))
         return tuple(x.value for x in v)
+
+    def permgen_note(self) -> str:
+        """Why the permutation generator left its block-parallel form ("" while it is in use); logged once as a warning."""
+        msg = c_char_p()
+        _check(self._lib.sc_ctx_permgen_note(self._h, byref(msg)))
+        note = (msg.value or b"").decode("utf-8", "replace")
+        if note and note != getattr(self, "_note_logged", ""):
+            self._note_logged = note
+            from spatialcore_amd._logging import get_logger
+
+            get_logger("device").warning(note)
+        return note
 
     def debug_copy(self, which: int, offset_bytes: int, count: int, dtype) -> np.ndarray:
         out = np.empty(count, dtype=dtype)
@@ -335,6 +358,16 @@ class Context:
     def generate_permutations(self, words: np.ndarray, n: int, n_perm: int, fetch: bool = False):
         out = np.empty((n_perm, n), dtype=np.int32) if fetch else None
         _check(self._lib.sc_perm_generate(self._h, _ptr(words), int(n), int(n_perm), _ptr(out)))
+        self.permgen_note()
+        return out
+
+    def generate_permutations_counter(self, seed: int, n: int, n_perm: int, p_first: int = 0, fetch: bool = False):
+        """EXTENSION: counter-based permutations p_first .. p_first + n_perm - 1 as the resident table (rows 0 ..):
+        permutation p is a pure function of (seed, p) -- Fisher-Yates with Philox4x32-10 + Lemire draws -- so ranks and
+        batches can take disjoint ranges.  For the paths that have no reference seed semantics only."""
+        out = np.empty((n_perm, n), dtype=np.int32) if fetch else None
+        _check(self._lib.sc_perm_generate_counter(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(n), int(p_first), int(n_perm),
+                                                  _ptr(out)))
         return out
 
     def set_permutations(self, perm) -> None:
@@ -364,6 +397,7 @@ class Context:
         ssq = np.zeros(G, dtype=np.float64)
         _check(self._lib.sc_moran_seeded(self._h, _ptr(words), int(n_perm), _ptr(I), _ptr(sims), _ptr(cnt),
                                          _ptr(ssum), _ptr(ssq)))
+        self.permgen_note()
         return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
 
     def lee(self, pair_x, pair_y, perm_offset, n_perm: int, return_perms: bool = False):
@@ -393,6 +427,7 @@ class Context:
         L = np.empty((gx.size, gy.size), dtype=np.float64)
         cnt = np.zeros((gx.size, gy.size), dtype=np.int64)
         Lp = np.empty((n_perm, gx.size, gy.size), dtype=np.float64) if return_perms else None
+        # words = None: rows [0, n_perm) of the resident table (e.g. generate_permutations_counter's)
         _check(self._lib.sc_lee_shared(self._h, _ptr(words), _ptr(gx), gx.size, _ptr(gy), gy.size, int(n_perm), _ptr(L), _ptr(cnt), _ptr(Lp)))
         return {"L": L, "count_abs_ge": cnt, "L_perm": Lp}
 

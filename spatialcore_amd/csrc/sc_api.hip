@@ -9,9 +9,12 @@ static thread_local char g_err[1024] = "";
 
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
 // streams that share a hardware queue run strictly one after the other.  The generator / scoring pipeline of
-// sc_moran_seeded uses nine streams whose kernels MUST overlap (a 25-ms scoring launch in front of the generator's
+// sc_moran_seeded uses nine streams whose kernels should overlap (a 25-ms scoring launch in front of the generator's
 // sub-millisecond chain launches doubles the step), so the library asks for one hardware queue per stream -- before
-// the runtime initialises, i.e. when the library is loaded, and only if the user has not set the variable.
+// the runtime initialises, i.e. when the library is loaded, and only if the user has not set the variable.  It is a
+// REQUEST, not a requirement: a host application that initialised HIP earlier (or set a smaller value) keeps its
+// setting; the generator probes its streams before its first block-parallel job (permgen_probe_streams), uses the
+// sequential scan when they cannot overlap, and says so through sc_ctx_permgen_note (logged once by the Python layer).
 __attribute__((constructor)) static void sc_request_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 void sc_set_error(const char *fmt, ...)
@@ -245,6 +248,18 @@ int sc_ctx_set_permgen_mode(sc_ctx *c, int mode)
     SC_REQUIRE(c, SC_ERR_INVALID, "null context");
     SC_REQUIRE(mode >= 0 && mode <= 2, SC_ERR_INVALID, "sc_ctx_set_permgen_mode: mode %d not in {0, 1, 2}", mode);
     c->pg_mode = mode;
+    // re-arm: a context that fell back to the sequential scan after one stalled hand-over (a transient: GPU shared with
+    // another process, a profiler pass) probes its streams again and may return to the block-parallel form
+    c->pg_streams_serial = false;
+    c->pg_probed = false;
+    c->pg_note.clear();
+    return SC_OK;
+}
+
+int sc_ctx_permgen_note(sc_ctx *c, const char **message)
+{
+    SC_REQUIRE(c && message, SC_ERR_INVALID, "null pointer");
+    *message = c->pg_note.c_str();   // "" while the block-parallel generator is in use; valid until the next generator call
     return SC_OK;
 }
 

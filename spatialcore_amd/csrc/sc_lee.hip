@@ -590,9 +590,11 @@ extern "C" int sc_lee_shared(sc_ctx *c, uint64_t *state6, const int32_t *genes_x
 {
     SC_REQUIRE(c && genes_x && genes_y && L_out && count_abs_ge_out, SC_ERR_INVALID, "sc_lee_shared: null pointer");
     SC_REQUIRE(n_x >= 1 && n_y >= 1 && n_perm >= 0, SC_ERR_INVALID, "sc_lee_shared: bad sizes");
-    SC_REQUIRE(n_perm == 0 || state6, SC_ERR_INVALID, "sc_lee_shared: generator state required when n_perm > 0");
     SC_HIP(hipSetDevice(c->device));
     SC_REQUIRE(c->e_n > 0 && c->g_n == c->e_n, SC_ERR_STATE, "sc_lee_shared: expression / graph missing");
+    // state6 == NULL: the shared block is rows [0, n_perm) of the RESIDENT table (e.g. sc_perm_generate_counter's)
+    SC_REQUIRE(n_perm == 0 || state6 || (c->p_count >= n_perm && c->p_n == c->e_n), SC_ERR_STATE,
+               "sc_lee_shared: no generator state and no resident table of %lld rows", (long long)n_perm);
     const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
     for (int k = 0; k < n_x; ++k) SC_REQUIRE(genes_x[k] >= 0 && genes_x[k] < G, SC_ERR_INVALID, "sc_lee_shared: x gene out of range");
     for (int k = 0; k < n_y; ++k) SC_REQUIRE(genes_y[k] >= 0 && genes_y[k] < G, SC_ERR_INVALID, "sc_lee_shared: y gene out of range");
@@ -674,10 +676,14 @@ extern "C" int sc_lee_shared(sc_ctx *c, uint64_t *state6, const int32_t *genes_x
             SC_HIP(hipGetLastError());
             return SC_OK;
         };
+        if (!state6) {   // the resident table, chunk by chunk
+            SC_TRY(sc_perm_forward_ensure(c));
+            for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) SC_TRY(score(p0, p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm));
+        }
         SC_HIP(hipMemcpyAsync(d_cnt_backup, c->lee_cnt.p, sizeof(unsigned long long) * (size_t)per, hipMemcpyDeviceToDevice, c->stream));
         const int ahead = c->pg_ahead;
         c->pg_ahead = 2;
-        int rc = sc_perm_pipeline(c, state6, n, n_perm, 0, nullptr, score);
+        int rc = state6 ? sc_perm_pipeline(c, state6, n, n_perm, 0, nullptr, score) : SC_OK;
         if (rc == SC_PERMGEN_RETRY) {
             SC_HIP(hipMemcpyAsync(c->lee_cnt.p, d_cnt_backup, sizeof(unsigned long long) * (size_t)per, hipMemcpyDeviceToDevice, c->stream));
             const int mode = c->pg_mode;

@@ -1453,6 +1453,20 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
 #define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
 #endif
 
+// permutations of the pipeline's first / last chunk (SC_PIPE_FIRST / SC_PIPE_LAST: development, to sweep the schedule)
+static int64_t pipe_first_perms()
+{
+    int64_t v = PIPE_FIRST;
+    if (const char *e = getenv("SC_PIPE_FIRST")) v = atoi(e);
+    return v < 8 || v > PERM_CHUNK ? PIPE_FIRST : v;
+}
+static int64_t pipe_last_perms()
+{
+    int64_t v = PIPE_LAST;
+    if (const char *e = getenv("SC_PIPE_LAST")) v = atoi(e);
+    return v < 0 || v > PERM_CHUNK ? PIPE_LAST : v;
+}
+
 // The generator / consumer pipeline shared by sc_moran_seeded and sc_lee_seeded: numpy-exact permutation rows
 // [0, n_perm) of length n are produced chunk by chunk on the generator's streams (stream2: rejection scan chain,
 // stream_pg: its preparation, stream_px: verification + expansion, stream3/4: Fisher-Yates swaps) while
@@ -1486,8 +1500,9 @@ int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int
     std::vector<int64_t> bounds;
     bounds.push_back(0);
     if (n_perm > 3 * PERM_CHUNK) {
-        const int64_t last = PIPE_LAST, rest = (n_perm - last - PIPE_FIRST) % PERM_CHUNK;
-        int64_t p = PIPE_FIRST + (rest < PERM_CHUNK / 2 ? rest : 0);  // a small remainder joins the first chunk
+        const int64_t first = pipe_first_perms(), last = pipe_last_perms();
+        const int64_t rest = (n_perm - last - first) % PERM_CHUNK;
+        int64_t p = first + (rest < PERM_CHUNK / 2 ? rest : 0);  // a small remainder joins the first chunk
         bounds.push_back(p);
         if (rest >= PERM_CHUNK / 2) { p += rest; bounds.push_back(p); }
         for (; p < n_perm - last; ) { p += PERM_CHUNK; bounds.push_back(p); }
@@ -1513,14 +1528,17 @@ int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int
         return SC_OK;
     };
     int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
-    // chunk k + 1 of the generator is enqueued ahead of the consumption of chunk k, so that neither side waits for the
-    // host to enqueue the other (a chunk is some 250 API calls)
+    // The generator is the longest chain of the job and depends on nothing else: its chunks are enqueued TWO ahead of
+    // the consumption (chunks 0 and 1 before the consumer's host-blocking set-up, which waits for the graph and the
+    // expression statistics; r03 timeline: the chain sat idle for 5 ms behind that set-up with one chunk ahead), so
+    // that neither side waits for the host to enqueue the other (a chunk is some 250 API calls)
     if (rc == SC_OK) rc = generate(0);
+    if (rc == SC_OK && chunks > 1) rc = generate(1);
     if (rc == SC_OK && after_first) rc = after_first();
     c->perm_bijective = true;  // device-generated rows are permutations by construction
     c->perm_forward_valid = table != 1;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
-        if (k + 1 < chunks) rc = generate(k + 1);
+        if (k + 2 < chunks) rc = generate(k + 2);
         if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("permutation pipeline: event plumbing failed");
             rc = SC_ERR_HIP;
@@ -1570,7 +1588,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
             int tail_prev = keep < 32 ? keep : 32, tail_last = 8;
             if (const char *v = getenv("SC_SCORE_LEAVE_TAIL")) sscanf(v, "%d,%d", &tail_prev, &tail_last);
             if (p1 == n_perm) c->score_leave_cus = tail_last;
-            else if (PIPE_LAST > 0 && n_perm - p1 <= PIPE_LAST) c->score_leave_cus = tail_prev;
+            else if (pipe_last_perms() > 0 && n_perm - p1 <= pipe_last_perms()) c->score_leave_cus = tail_prev;
         }
         const int rc = moran_perm_range(c, p0, p1, bits, false);
         c->score_leave_cus = keep;

@@ -723,12 +723,12 @@ __device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_
 // in device memory:  flags[1 + u % 16] = u + 1 once unit u is prepared (k_publish, behind the unit's preparation
 // launches in their stream), flags[0] = number of units the chain has completed (k_chain, after each unit; the
 // preparation of unit u starts behind k_gate, one wavefront that waits for flags[0] >= u - ahead).
-// Every wait gives up after 10 s or when a failure flag is up (e.g. when the streams do not run concurrently: a
+// Every wait gives up after 1 s or when a failure flag is up (e.g. when the streams do not run concurrently: a
 // profiler that serialises kernels, fewer hardware queues than streams) and raises flag 8 / 16: the caller then
 // reruns the job with the sequential scan, as after a failed verification.
 // ------------------------------------------------------------------------------------------------
 #define PHI_FLAG_SLOTS 16
-#define PHI_WAIT_TICKS 1000000000ll   // 10 s of the 100 MHz wall clock (a chunk of 128 permutations of 3 x 10^7 cells takes ~1 s)
+#define PHI_WAIT_TICKS 100000000ll    // 1 s of the 100 MHz wall clock; a wait is for ONE launch unit (512 blocks, ~1 ms of work at any n)
 
 // 0: the word arrived; 1: gave up waiting (the caller raises its flag); 2: abandoned, a failure flag is up already
 __device__ __forceinline__ int phi_wait_at_least(const uint32_t *flag, uint32_t want, const unsigned long long *st)
@@ -750,6 +750,54 @@ __global__ void k_publish(uint32_t *flags, uint32_t slot, uint32_t value)
 __global__ void k_gate(const uint32_t *flags, uint32_t chain_units_needed, unsigned long long *st)
 {
     if (threadIdx.x == 0 && phi_wait_at_least(flags, chain_units_needed, st) == 1) atomicOr(st + 2, 16ull);
+}
+
+// Can the generator's streams run concurrently?  The hand-over words need the chain's stream and the four preparation
+// streams on different hardware queues (GPU_MAX_HW_QUEUES; a profiler that serialises kernels breaks it too).  Probed
+// ONCE per context, before the first block-parallel job, instead of finding out through a one-second give-up inside a
+// job: in five rounds each stream in turn hosts a setter kernel that is enqueued LAST, behind waiters on the other four;
+// two streams that share a queue deadlock in the round where the waiter of the pair sits in front of the setter, and
+// that waiter gives up after 5 ms.
+__global__ void k_probe_wait(const uint32_t *flag, uint32_t want, uint32_t *timed_out)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (wall_clock64() - t0 > 500000ll) { atomicOr(timed_out, 1u); return; }   // 5 ms
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
+{
+    if (c->pg_probed) return SC_OK;
+    c->pg_probed = true;
+    std::vector<hipStream_t> ss;
+    ss.push_back(chain_stream);
+    for (hipStream_t sp : c->stream_pg)
+        if (sp && sp != chain_stream) ss.push_back(sp);
+    SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
+    uint32_t *words = c->perm_flag.as<uint32_t>();
+    SC_HIP(hipDeviceSynchronize());
+    SC_HIP(hipMemset(words, 0, 2 * sizeof(uint32_t)));
+    for (size_t setter = 0; setter < ss.size(); ++setter) {
+        for (size_t k = 0; k < ss.size(); ++k)
+            if (k != setter) hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, ss[k], words, (uint32_t)(setter + 1), words + 1);
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ss[setter], words, 0u, (uint32_t)(setter + 1));
+        for (hipStream_t sp : ss) SC_HIP(hipStreamSynchronize(sp));
+    }
+    uint32_t host[2] = {0, 0};
+    SC_HIP(hipMemcpy(host, words, sizeof(host), hipMemcpyDeviceToHost));
+    if (host[1]) {
+        c->pg_streams_serial = true;
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        char buf[320];
+        snprintf(buf, sizeof(buf), "the HIP streams of this process do not run concurrently (GPU_MAX_HW_QUEUES=%s; the library "
+                 "asks for 16 when it is loaded BEFORE the HIP runtime initialises, or a profiler serialises kernels): the "
+                 "permutation generator uses its sequential scan (same results, about half the speed)", q ? q : "unset");
+        c->pg_note = buf;
+    }
+    return SC_OK;
 }
 
 // Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
@@ -1278,6 +1326,12 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     job->phi = permgen_is_block_parallel(c, n);
     job->B_done = 0; job->unit_no = 0;
     job->ahead = c->pg_ahead >= 1 && c->pg_ahead <= PHI_AHEAD_MAX ? c->pg_ahead : 1;
+    if (job->phi && !c->pg_probed) {   // first block-parallel job of this context: can its streams overlap at all?
+        for (hipStream_t &sp : c->stream_pg)
+            if (!sp) SC_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+        SC_TRY(permgen_probe_streams(c, s));
+        job->phi = permgen_is_block_parallel(c, n);
+    }
     if (job->phi) {
         SC_TRY(c->pg_desc.ensure(sizeof(PhiDesc) * (size_t)PHI_RING, &c->mem));
         SC_TRY(c->pg_tbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
@@ -1456,7 +1510,12 @@ int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
     if (job->phi) { c->pg_blocks_prepared += (int64_t)st[4]; c->pg_blocks_chain += (int64_t)st[5]; }
     if (job->phi && st[2] != 0) {  // verification of the block-parallel scan failed: the caller reruns sequentially
         c->pg_fallbacks += 1;
-        if (st[2] & 24ull) c->pg_streams_serial = true;  // a hand-over wait gave up (flags 8 / 16)
+        if (st[2] & 24ull) {   // a hand-over wait gave up (flags 8 / 16): later jobs take the sequential scan at once
+            c->pg_streams_serial = true;
+            c->pg_note = "a hand-over wait of the block-parallel permutation generator gave up after 1 s (kernels of its streams did "
+                         "not overlap: GPU shared with another process, a profiler, too few hardware queues); this context now uses "
+                         "the sequential scan (same results); sc_ctx_set_permgen_mode(ctx, 0) re-arms the block-parallel form";
+        }
         sc_set_error("sc_perm_generate: block-parallel scan failed its verification (flags %llu)", st[2]);
         return SC_PERMGEN_RETRY;
     }
@@ -1480,6 +1539,104 @@ int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
     } else if (pos == 1 && h == 1) {
         state6[4] = 0;  // only the buffered half was consumed; uinteger keeps its value
     }
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based permutations (r03; SURVEY 8(e) "alternative", H2) for the paths that have NO reference seed semantics
+// (label-permutation enrichment, shared-permutation Lee grids): permutation p is a pure function of (seed, p), so ranks
+// and batches can take disjoint ranges of p and merge integer counts.  Definition (documented, reproducible, the same
+// on any number of GPUs): Fisher-Yates as numpy runs it -- for i = n-1 .. 1: j uniform on [0, i]; swap a[i], a[j] -- with
+//   j = bounded(Philox4x32-10(key = (seed low word, seed high word), counter = (i, r, p low, p high)), i + 1)
+// where the first two output words form a 64-bit u and bounded is Lemire's multiply-shift with its exact rejection
+// (u * (i + 1) >> 64, rejected -- retry with r + 1 -- when the low half falls below 2^64 mod (i + 1): probability < 2^-43
+// per draw, so r is 0 in practice and the draw stays a pure function of its counter).  No sequential stage at all: J is
+// filled by the whole chip, the swaps are the generator's stage B.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ static inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__host__ __device__ static inline uint32_t counter_bounded(uint32_t k0, uint32_t k1, uint64_t p, uint32_t i)
+{
+    const uint64_t range = (uint64_t)i + 1;
+    for (uint32_t r = 0;; ++r) {
+        uint32_t c[4] = {i, r, (uint32_t)p, (uint32_t)(p >> 32)};
+        philox4x32_10(c, k0, k1);
+        const uint64_t u = ((uint64_t)c[1] << 32) | c[0];
+        const u128 m = (u128)u * range;
+        const uint64_t low = (uint64_t)m;
+        if (low >= range || low >= (0 - range) % range) return (uint32_t)(m >> 64);
+    }
+}
+
+// J[(p - p_first) * M + (M - i)] = the swap partner of step i of permutation p (the layout stage B reads)
+__global__ __launch_bounds__(256) void k_counter_J(uint32_t k0, uint32_t k1, uint32_t n, uint64_t p_first, int64_t n_perm,
+                                                   int32_t *__restrict__ J)
+{
+    const uint32_t M = n - 1;
+    const int64_t total = n_perm * (int64_t)M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / M;
+        const uint32_t s = (uint32_t)(t - p * M);
+        J[t] = (int32_t)counter_bounded(k0, k1, p_first + (uint64_t)p, M - s);
+    }
+}
+
+extern "C" int sc_perm_counter_host(uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, int32_t *perm_out)
+{
+    SC_REQUIRE(perm_out || n_perm == 0 || n == 0, SC_ERR_INVALID, "sc_perm_counter_host: null pointer");
+    SC_REQUIRE(n >= 0 && n <= 0x7fffffffLL && n_perm >= 0 && p_first >= 0, SC_ERR_INVALID, "sc_perm_counter_host: bad sizes");
+    for (int64_t p = 0; p < n_perm; ++p) {
+        int32_t *a = perm_out + p * n;
+        for (int64_t i = 0; i < n; ++i) a[i] = (int32_t)i;
+        for (int64_t i = n - 1; i >= 1; --i) {
+            const uint32_t j = counter_bounded((uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)(p_first + p), (uint32_t)i);
+            const int32_t t = a[j]; a[j] = a[i]; a[i] = t;
+        }
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_perm_generate_counter(sc_ctx *c, uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, int32_t *perm_out)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "sc_perm_generate_counter: null context");
+    SC_REQUIRE(p_first >= 0, SC_ERR_INVALID, "sc_perm_generate_counter: negative first permutation");
+    SC_HIP(hipSetDevice(c->device));
+    SC_TRY(sc_perm_alloc(c, n, n_perm));
+    if (n == 1) {
+        SC_HIP(hipMemsetAsync(c->perm.p, 0, sizeof(int32_t) * (size_t)(c->p_stride * n_perm), c->stream));
+    } else {
+        const int64_t M = n - 1;
+        SC_TRY(c->pg_J.ensure(sizeof(int32_t) * (size_t)(M * n_perm + 64), &c->mem));
+        KernelTimerScope ts(c, SC_K_PERMGEN);
+        const int64_t total = M * n_perm;
+        const unsigned grid = (unsigned)(ceil_div64(total, 256) < 65536 ? ceil_div64(total, 256) : 65536);
+        hipLaunchKernelGGL(k_counter_J, dim3(grid), dim3(256), 0, c->stream, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)n,
+                           (uint64_t)p_first, n_perm, c->pg_J.as<int32_t>());
+        if (n >= SWAPS_WG_MIN_N)
+            hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)n_perm), dim3(SW_T), 0, c->stream, c->pg_J.as<int32_t>(),
+                               c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
+        else
+            hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)n_perm), dim3(64), 0, c->stream, c->pg_J.as<int32_t>(),
+                               c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
+        SC_HIP(hipGetLastError());
+    }
+    c->p_count = n_perm;
+    c->perm_bijective = true;
+    c->perm_forward_valid = true;
+    if (perm_out)
+        SC_HIP(hipMemcpy2DAsync(perm_out, sizeof(int32_t) * (size_t)n, c->perm.p, sizeof(int32_t) * (size_t)c->p_stride,
+                                sizeof(int32_t) * (size_t)n, (size_t)n_perm, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }
 

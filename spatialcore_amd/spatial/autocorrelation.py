@@ -427,6 +427,7 @@ def lees_l(
     device: int = 0,
     radius: Optional[float] = None,
     shared_permutations: bool = False,
+    rng: str = "numpy",
 ) -> Union[dict, List[dict]]:
     """Global Lee's L bivariate spatial association with permutation p-values (AC:991-1163).
 
@@ -445,6 +446,8 @@ def lees_l(
     are no longer the reference's for the same seed (pairs after the first see other permutations there); in exchange
     a 100 x 100 screen at 1M cells costs seconds instead of minutes: the permutation statistics of the whole
     (distinct x genes) x (distinct y genes) grid become dense fp64 contractions on the matrix cores.
+    ``rng="philox"`` (with ``shared_permutations=True`` only: that mode has no reference seed semantics to keep) draws
+    the shared block from the counter-based source (``sc_perm_generate_counter``) instead of the numpy stream.
     """
     start_time = time.time()
     coords = _require_spatial(adata, spatial_key)
@@ -454,6 +457,9 @@ def lees_l(
     missing = all_genes - set(adata.var_names)
     if missing:
         raise ValueError(f"Genes not found in adata.var_names: {list(missing)}")
+    if rng not in ("numpy", "philox") or (rng == "philox" and not shared_permutations):
+        raise ValueError("rng must be 'numpy', or 'philox' together with shared_permutations=True "
+                         "(per-pair permutations follow the reference's numpy stream)")
     n_cells, n_pairs = adata.n_obs, len(gene_pairs)
     logger.info(f"Computing Global Lee's L: {n_cells:,} cells, {n_pairs} pair(s), "
                 f"k={n_neighbors}, permutations={n_permutations}")
@@ -475,7 +481,11 @@ def lees_l(
     if shared_permutations:
         xs, xi = np.unique(pair_slots[:, 0], return_inverse=True)
         ys, yi = np.unique(pair_slots[:, 1], return_inverse=True)
-        grid = ctx.lee_shared(words, xs, ys, n_permutations)
+        if rng == "philox" and n_permutations > 0:
+            ctx.generate_permutations_counter(seed, n_cells, n_permutations)
+            grid = ctx.lee_shared(None, xs, ys, n_permutations)
+        else:
+            grid = ctx.lee_shared(words, xs, ys, n_permutations)
         L, cnt = grid["L"][xi, yi], grid["count_abs_ge"][xi, yi]
     else:
         out = ctx.lee_seeded(words, pair_slots[:, 0], pair_slots[:, 1], n_permutations)

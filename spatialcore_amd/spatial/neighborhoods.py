@@ -150,6 +150,8 @@ def neighborhood_enrichment(
     *,
     device: int = 0,
     perm_batch: int = 512,
+    rng: str = "numpy",
+    comm=None,
 ):
     """Cell-type pair enrichment of the neighbourhood graph under label permutations.
 
@@ -157,16 +159,27 @@ def neighborhood_enrichment(
     composition profiles and k-means niches); BASELINE.json's config 5 asks for it.  Semantics
     defined here: on the same neighbour graph ``compute_neighborhood_profile`` uses,
     ``count[a, b]`` = number of edges cell -> neighbour with types (a, b); the null is drawn by
-    permuting the label vector with the numpy-exact stream ``default_rng(seed).permutation(n_cells)``
-    (``labels[perm]``), ``n_permutations`` times.  Stored in ``adata.uns[key_added]``:
-    ``count``, ``mean``, ``std`` (population), ``zscore = (count - mean) / std``,
+    permuting the label vector (``labels[perm]``) ``n_permutations`` times.  Stored in
+    ``adata.uns[key_added]``: ``count``, ``mean``, ``std`` (population), ``zscore = (count - mean) / std``,
     ``p_value = (#{perm count >= count} + 1) / (P + 1)`` as (T, T) arrays and ``celltypes``.
+
+    ``rng``: ``"numpy"`` (default) -- the numpy-exact stream ``default_rng(seed).permutation(n_cells)``, sequential by
+    nature: one GPU, generator-bound.  ``"philox"`` -- counter-based permutations (permutation p is a pure function of
+    ``(seed, p)``: Fisher-Yates with Philox4x32-10 + Lemire draws, ``sc_perm_generate_counter``); there is no reference
+    result to be seed-exact to here, and this source has no sequential stage.  With ``rng="philox"`` and ``comm`` (a
+    communicator from ``spatialcore_amd.parallel.connect``) the permutations are SHARDED over the ranks of the launch
+    (rank r takes ``shard_bounds(P, world, r)``) and the integer sums are merged with one all-reduce: every rank ends
+    with the same table, identical to a one-rank run.
     """
     problem = _request_problem(adata, celltype_column, method, k, radius, spatial_key)
     if problem:
         raise ValueError(problem)
     if n_permutations < 0:
         raise ValueError(f"n_permutations must be >= 0, got {n_permutations}")
+    if rng not in ("numpy", "philox"):
+        raise ValueError(f"rng must be 'numpy' or 'philox', got '{rng}'")
+    if comm is not None and comm.world > 1 and rng != "philox":
+        raise ValueError("permutations can only be sharded over ranks with rng='philox': the numpy stream is sequential")
     if copy:
         adata = adata.copy()
     n_cells = adata.n_obs
@@ -179,32 +192,45 @@ def neighborhood_enrichment(
     ctx = _lib.default_context(device)
     _activate_neighbour_graph(ctx, coords, method, k, radius)
 
-    words = _lib.rng_state_words(np.random.default_rng(seed))
+    words = _lib.rng_state_words(np.random.default_rng(seed)) if rng == "numpy" else None
+    lo, hi = 0, n_permutations
+    if comm is not None and comm.world > 1:
+        from spatialcore_amd.parallel import shard_bounds
+
+        lo, hi = shard_bounds(n_permutations, comm.world, comm.rank)
     observed = None
-    s1 = np.zeros((T, T), dtype=np.float64)
-    s2 = np.zeros((T, T), dtype=np.float64)
+    # integer sums of the deviations (null - observed) and of their squares, and the exceedance counts: exact and
+    # order-free, so permutation shards merge with an integer all-reduce
+    s1 = np.zeros((T, T), dtype=np.int64)
+    s2 = np.zeros((T, T), dtype=np.int64)
     ge = np.zeros((T, T), dtype=np.int64)
-    done = 0
+    done = lo
     while True:
-        batch = min(perm_batch, n_permutations - done)
+        batch = min(perm_batch, hi - done)
         if batch > 0:
-            ctx.generate_permutations(words, n_cells, batch)   # one stream, continued batch after batch
+            if rng == "numpy":
+                ctx.generate_permutations(words, n_cells, batch)   # one stream, continued batch after batch
+            else:
+                ctx.generate_permutations_counter(seed, n_cells, batch, p_first=done)
         cnt = ctx.enrichment_counts(codes, T, batch)
         observed = cnt[batch]
-        null = cnt[:batch].astype(np.float64)
-        s1 += null.sum(axis=0)
-        s2 += (null * null).sum(axis=0)
-        ge += (cnt[:batch] >= observed).sum(axis=0)
+        dev = cnt[:batch] - observed
+        s1 += dev.sum(axis=0)
+        s2 += (dev * dev).sum(axis=0)
+        ge += (dev >= 0).sum(axis=0)
         done += batch
-        if done >= n_permutations:
+        if done >= hi:
             break
-    result = {"count": observed, "celltypes": list(celltypes), "n_permutations": n_permutations, "seed": seed}
+    if comm is not None and comm.world > 1:
+        s1, s2, ge = comm.sum_over_ranks_i64(np.stack([s1, s2, ge]))     # the one collective of this path
+    result = {"count": observed, "celltypes": list(celltypes), "n_permutations": n_permutations, "seed": seed, "rng": rng}
     if n_permutations > 0:
-        mean = s1 / n_permutations
-        var = np.maximum(s2 / n_permutations - mean * mean, 0.0)
+        mean_dev = s1 / n_permutations
+        var = np.maximum(s2 / n_permutations - mean_dev * mean_dev, 0.0)
         std = np.sqrt(var)
+        mean = observed + mean_dev
         with np.errstate(divide="ignore", invalid="ignore"):
-            z = (observed - mean) / std
+            z = -mean_dev / std
         result.update({"mean": mean, "std": std, "zscore": z, "p_value": (ge + 1) / (n_permutations + 1)})
     adata.uns[key_added] = result
     update_metadata(
@@ -212,7 +238,7 @@ def neighborhood_enrichment(
         function_name="neighborhood_enrichment",
         parameters={"celltype_column": celltype_column, "method": method, "k": k if method == "knn" else None,
                     "radius": radius if method == "radius" else None, "n_permutations": n_permutations,
-                    "seed": seed, "spatial_key": spatial_key},
+                    "seed": seed, "spatial_key": spatial_key, "rng": rng},
         outputs={"uns": key_added, "n_celltypes": T, "n_cells": n_cells},
     )
     return adata

@@ -90,6 +90,51 @@ def test_bench_two_rank_rehearsal_prints_one_valid_line(tmp_path):
     assert line["scaling"] == "strong" and line["config"]["genes_total"] == 70 and line["config"]["genes_per_gpu"] == 35
 
 
+_ENRICH_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+from conftest import make_adata
+from spatialcore_amd import _lib
+from spatialcore_amd.parallel import connect, device_turn, world_info
+from spatialcore_amd.spatial import neighborhood_enrichment
+rank, world, _ = world_info()
+rng = np.random.default_rng(4)
+n, T, P = 60000, 7, 45
+coords = rng.uniform(0, 2500, (n, 2))
+labels = np.array([f"t{{c}}" for c in rng.integers(0, T, n)])
+comm = connect(None, transport="file")
+ad = make_adata(coords, np.zeros((n, 1)), labels=labels)
+with device_turn():
+    neighborhood_enrichment(ad, "cell_type", k=10, n_permutations=P, seed=8, perm_batch=16, rng="philox", comm=comm)
+    _lib.default_context(0).sync()
+solo = make_adata(coords, np.zeros((n, 1)), labels=labels)
+with device_turn():
+    neighborhood_enrichment(solo, "cell_type", k=10, n_permutations=P, seed=8, perm_batch=512, rng="philox")
+    _lib.default_context(0).sync()
+a, b = ad.uns["neighborhood_enrichment"], solo.uns["neighborhood_enrichment"]
+for key in ("count", "mean", "std", "zscore", "p_value"):
+    np.testing.assert_array_equal(a[key], b[key], err_msg=key)        # permutation shards merge to the one-rank result
+try:
+    neighborhood_enrichment(ad, "cell_type", k=10, n_permutations=4, comm=comm)
+    raise SystemExit("the numpy stream must refuse to be sharded")
+except ValueError:
+    pass
+comm.close()
+open(os.path.join(os.environ["SC_TEST_OUT"], f"ok_{{rank}}"), "w").write("ok")
+"""
+
+
+def test_two_ranks_shard_the_permutations_of_the_enrichment_philox(tmp_path):
+    """BASELINE configs[4]'s multi-GPU form (SURVEY 8(e) "alternative"): with the counter-based source rank r scores
+    permutations shard_bounds(P, 2, r) and ONE integer all-reduce merges the sums -- the table equals a one-rank run bit
+    for bit (two ranks with the HIP compute on one GPU, file transport: RCCL refuses duplicate devices)."""
+    script = tmp_path / "enrich_worker.py"
+    script.write_text(_ENRICH_WORKER.format(root=ROOT))
+    _launch_two(lambda rank: [sys.executable, str(script)], tmp_path)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
 def test_bench_launches_its_own_ranks_without_a_launcher(tmp_path):
     """`python bench.py --gpus 2 ...` exactly as the driver invokes the bench for N = 1, no torchrun in front: the
     parent starts the two ranks itself (fresh processes; it never touches the GPU) and relays rank 0's one JSON line."""
@@ -147,15 +192,16 @@ for rep in range(2):
 par, seq, fallbacks = ctx.permgen_stats()[:3]
 for key in ("I", "sims", "count_ge"):
     np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
+print("NOTE", ctx.permgen_note(), flush=True)
 print("STATS", par, seq, fallbacks, walls[0], walls[1], flush=True)
 """
 
 
-def test_generator_without_concurrent_streams_falls_back_once(tmp_path):
+def test_generator_without_concurrent_streams_uses_the_sequential_scan(tmp_path):
     """The block-parallel generator orders its launches through words in device memory, which needs its streams to run
-    concurrently.  With two hardware queues for a dozen streams they cannot: the first job must notice (its waits give
-    up after 10 s), rerun with the sequential scan and return the numpy-exact result; the context must then stay with
-    the sequential form (no second wait)."""
+    concurrently.  With two hardware queues for a dozen streams they cannot: the context's one-off probe (r03) notices
+    within milliseconds -- or, should the probe's streams happen to overlap, the first job's waits give up after 1 s --,
+    the sequential scan returns the numpy-exact result, and the reason is reported (sc_ctx_permgen_note)."""
     script = tmp_path / "serial_worker.py"
     script.write_text(_SERIAL_WORKER.format(root=ROOT))
     env = dict(os.environ, GPU_MAX_HW_QUEUES="2")
@@ -163,7 +209,9 @@ def test_generator_without_concurrent_streams_falls_back_once(tmp_path):
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     stats = [ln for ln in run.stdout.splitlines() if ln.startswith("STATS")][-1].split()
     par, seq, fallbacks, first, second = int(stats[1]), int(stats[2]), int(stats[3]), float(stats[4]), float(stats[5])
-    if fallbacks == 0:
+    note = [ln for ln in run.stdout.splitlines() if ln.startswith("NOTE")][-1]
+    if (par, seq, fallbacks) == (2, 0, 0):
         pytest.skip("the runtime ran the streams concurrently on two hardware queues: nothing to fall back from")
-    assert (par, seq, fallbacks) == (0, 2, 1), stats
-    assert first > 9.0 and second < 5.0, stats     # one 10-s give-up, then the sequential form at once
+    assert (par, seq) == (0, 2) and fallbacks in (0, 1), stats    # 0: caught by the probe; 1: by a give-up inside the first job
+    assert "sequential scan" in note and "GPU_MAX_HW_QUEUES=2" in note or fallbacks == 1, note
+    assert first < 6.0 and second < 5.0, stats      # no 10-s stall any more

@@ -383,3 +383,44 @@ def test_neighborhood_enrichment_extension(oracle):
         assert res["zscore"][ia, ia] > 3 and res["zscore"][ia, ic] < -3     # same-side types attract
     with pytest.raises(ValueError, match="Invalid method"):
         neighborhood_enrichment(ad, "cell_type", method="grid")
+    # rng="philox": the counter-based source (sc_perm_generate_counter), permutation p a pure function of (seed, p);
+    # against the oracle's restatement of that definition (numpy Philox4x32-10 pinned by Random123's known answers)
+    ad = make_adata(coords, X, labels=labels)
+    neighborhood_enrichment(ad, "cell_type", method="knn", k=8, n_permutations=21, seed=77, perm_batch=8, rng="philox")
+    res = ad.uns["neighborhood_enrichment"]
+    nbr = oracle.knn_bruteforce(coords, 8)
+    perms = np.stack([oracle.counter_permutation(77, n, p) for p in range(21)])
+    want = oracle.enrichment_counts(np.arange(0, n * 8 + 1, 8), nbr.reshape(-1), codes, len(cats), perms)
+    np.testing.assert_array_equal(res["count"], want[-1])
+    np.testing.assert_array_equal(res["p_value"], ((want[:-1] >= want[-1]).sum(axis=0) + 1) / 22)
+    np.testing.assert_allclose(res["mean"], want[:-1].astype(float).mean(axis=0), rtol=1e-12)
+    np.testing.assert_allclose(res["std"], want[:-1].astype(float).std(axis=0), rtol=1e-9, atol=1e-9)
+    with pytest.raises(ValueError, match="rng must be"):
+        neighborhood_enrichment(ad, "cell_type", rng="mt19937")
+
+
+def test_counter_permutations_on_the_device_and_lee_shared_philox(oracle):
+    """The device's counter-based table equals the host definition (both long-permutation swap forms), and
+    lees_l(shared_permutations=True, rng="philox") scores exactly those rows."""
+    from spatialcore_amd import _lib
+    from spatialcore_amd.spatial import lees_l
+
+    ctx = _lib.default_context(0)
+    for n, P, p0 in [(1, 3, 0), (2, 5, 1), (1000, 9, 4), (70001, 6, 2**33 + 1)]:
+        got = ctx.generate_permutations_counter(123, n, P, p_first=p0, fetch=True)
+        np.testing.assert_array_equal(got, _lib.perm_counter_host(123, n, P, p_first=p0))
+    n, G, P = 4000, 6, 19
+    coords, X = synth(n, G, 9, dtype=np.float64, sparse_x=False)
+    ad = make_adata(coords, X)
+    pairs = [("g0", "g3"), ("g1", "g4"), ("g2", "g5"), ("g0", "g5")]
+    res = lees_l(ad, pairs, n_neighbors=6, n_permutations=P, seed=31, shared_permutations=True, rng="philox")
+    perms = _lib.perm_counter_host(31, n, P)
+    W = oracle.reference_weights(coords, 6).astype(np.float64)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    for r, (a, b) in zip(res, [(0, 3), (1, 4), (2, 5), (0, 5)]):
+        L = float(Z[:, a] @ (W @ Z[:, b]))
+        Lp = np.array([float(Z[:, a] @ (W @ Z[perms[p], b])) for p in range(P)])
+        assert r["L"] == pytest.approx(L, rel=1e-9)
+        assert r["p_value"] == ((np.abs(Lp) >= abs(L)).sum() + 1) / (P + 1)
+    with pytest.raises(ValueError, match="rng must be"):
+        lees_l(ad, pairs, n_permutations=3, rng="philox")           # per-pair permutations follow numpy's stream

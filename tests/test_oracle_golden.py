@@ -190,3 +190,28 @@ def test_moran_restatement_cross_checks(oracle):
     I_glob = oracle.morans_i_scores(csr_matrix(W, dtype=np.float64), Xl.T.copy())
     local_sum = gl["c2_I"].astype(np.float64).sum(axis=0) / Xl.shape[0]
     np.testing.assert_allclose(I_glob, local_sum, rtol=2e-4, atol=2e-6)  # float32 reference arrays
+
+
+def test_counter_based_permutation_source_philox_kat_and_host_generator(oracle):
+    """The counter-based source (an EXTENSION for paths without reference seed semantics): the oracle's numpy
+    Philox4x32-10 reproduces Random123's published known answers, and the library's host generator
+    (sc_perm_counter_host, the same code the device kernel compiles) equals the oracle's restatement of the whole
+    definition (Philox -> Lemire -> Fisher-Yates) -- including that permutation p does not depend on where a range starts."""
+    from spatialcore_amd import _lib
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = oracle.philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    for seed, n, p0, cnt in [(0, 10, 0, 4), (12345678901234567, 257, 3, 3), (7, 1, 0, 2), (7, 2, 9, 5), (2**63 + 5, 1000, 2**33, 2)]:
+        got = _lib.perm_counter_host(seed, n, cnt, p_first=p0)
+        for k in range(cnt):
+            np.testing.assert_array_equal(got[k], oracle.counter_permutation(seed, n, p0 + k))
+            assert sorted(got[k].tolist()) == list(range(n))
+    a = _lib.perm_counter_host(3, 500, 6, p_first=0)
+    b = _lib.perm_counter_host(3, 500, 2, p_first=4)
+    np.testing.assert_array_equal(a[4:], b)                   # a pure function of (seed, p)
+    assert not (a[0] == a[1]).all() and not (a[0] == _lib.perm_counter_host(4, 500, 1)[0]).all()
