@@ -558,15 +558,52 @@ __global__ __launch_bounds__(256) void k_edge_rows(const long long *__restrict__
     for (long long e = indptr[i]; e < indptr[i + 1]; ++e) erow_r[e] = r;
 }
 
-// The graph setters call this: if the points of the last neighbour search are the graph's cells (same count), their
-// bin-sorted order is kept with the graph; otherwise the identity.  A wrong guess costs speed, never correctness.
+// Morton (Z-curve) key of a point: 16 bits per axis over the bin grid's extent, x in the even bits
+__device__ __forceinline__ uint32_t spread16(uint32_t v)
+{
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
+                                                     double x0, double y0, double inv_ext, uint32_t *__restrict__ keys,
+                                                     int32_t *__restrict__ ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double fx = (x[i] - x0) * inv_ext * 65536.0, fy = (y[i] - y0) * inv_ext * 65536.0;
+    fx = fx < 0.0 ? 0.0 : (fx > 65535.0 ? 65535.0 : fx);
+    fy = fy < 0.0 ? 0.0 : (fy > 65535.0 ? 65535.0 : fy);
+    keys[i] = spread16((uint32_t)fx) | (spread16((uint32_t)fy) << 1);
+    ids[i] = (int32_t)i;
+}
+
+// The graph setters call this: if the points of the last neighbour search are the graph's cells (same count), a
+// spatially compact processing order is kept with the graph -- the cells along a Morton (Z) curve over the bin grid's
+// extent (r03; r02 kept the row-major bin order of the neighbour search, whose rows are ~3000 cells long at 1M cells:
+// a cell's neighbours in the bin rows above / below were 120 KB away and came from other XCDs' L2s) --, otherwise the
+// identity.  A wrong guess costs speed, never correctness: it is only the order in which kernels that gather
+// neighbours' rows (k_lag, local Moran, enrichment) walk the cells.
 int sc_graph_capture_order(sc_ctx *c, int64_t n)
 {
     c->g_order_ready = false;
     SC_TRY(c->g_order.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
-    if (c->pts_n == n && c->sid.p)
-        SC_HIP(hipMemcpyAsync(c->g_order.p, c->sid.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    else
+    if (c->pts_n == n && c->px.p && c->py.p && c->bin_keys.p && c->bin_keys2.p && c->sid2.p) {
+        const double ext = (double)(c->nbx > c->nby ? c->nbx : c->nby) * c->gh;
+        hipLaunchKernelGGL(k_morton_keys, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->px.as<double>(),
+                           c->py.as<double>(), n, c->gx0, c->gy0, ext > 0.0 ? 1.0 / ext : 0.0, c->bin_keys.as<uint32_t>(),
+                           c->sid2.as<int32_t>());
+        size_t tmp_bytes = 0;
+        SC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->bin_keys.as<uint32_t>(), c->bin_keys2.as<uint32_t>(),
+                                                  c->sid2.as<int32_t>(), c->g_order.as<int32_t>(), (int)n, 0, 32, c->stream));
+        SC_TRY(c->cub_tmp.ensure(tmp_bytes, &c->mem));
+        SC_HIP(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp_bytes, c->bin_keys.as<uint32_t>(), c->bin_keys2.as<uint32_t>(),
+                                                  c->sid2.as<int32_t>(), c->g_order.as<int32_t>(), (int)n, 0, 32, c->stream));
+    } else
         hipLaunchKernelGGL(k_iota32, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->g_order.as<int32_t>(), n);
     SC_HIP(hipGetLastError());
     c->g_order_captured = true;

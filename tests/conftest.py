@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test gets a wall-clock limit (pytest-timeout, when installed): a test that waits for something that
+    never comes fails with a traceback after 6 minutes instead of holding the GPU box until it is killed."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(360))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _native_built():
     """Build libspatialcore_hip.so (hipcc cross-compiles without a GPU) and liboracle.so if they are

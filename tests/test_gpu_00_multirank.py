@@ -103,11 +103,26 @@ rng = np.random.default_rng(4)
 n, T, P = 60000, 7, 45
 coords = rng.uniform(0, 2500, (n, 2))
 labels = np.array([f"t{{c}}" for c in rng.integers(0, T, n)])
-comm = connect(None, transport="file")
+class TurnComm:
+    # The two ranks share ONE GPU and take turns on it; the collective must run OUTSIDE a rank's turn, or the rank that
+    # holds the GPU waits for the other, which waits for the GPU.  (One process per GPU -- the deployment -- has no turns.)
+    def __init__(self, inner, turn):
+        self.inner, self.turn, self.world, self.rank = inner, turn, inner.world, inner.rank
+    def sum_over_ranks_i64(self, values):
+        _lib.default_context(0).sync()
+        self.turn.__exit__(None, None, None)
+        try:
+            return self.inner.sum_over_ranks_i64(values)
+        finally:
+            self.turn.__enter__()
+inner = connect(None, transport="file")
 ad = make_adata(coords, np.zeros((n, 1)), labels=labels)
-with device_turn():
-    neighborhood_enrichment(ad, "cell_type", k=10, n_permutations=P, seed=8, perm_batch=16, rng="philox", comm=comm)
+turn = device_turn()
+with turn:
+    neighborhood_enrichment(ad, "cell_type", k=10, n_permutations=P, seed=8, perm_batch=16, rng="philox",
+                            comm=TurnComm(inner, turn))
     _lib.default_context(0).sync()
+comm = inner
 solo = make_adata(coords, np.zeros((n, 1)), labels=labels)
 with device_turn():
     neighborhood_enrichment(solo, "cell_type", k=10, n_permutations=P, seed=8, perm_batch=512, rng="philox")
