@@ -273,7 +273,9 @@ def main() -> None:
     else:
         g_lo, G_total, G_mine = rank * genes_arg, genes_arg * world, genes_arg
 
-    ctx = _lib.Context(local_rank)
+    # the process-wide context of the device: the AnnData-level morans_i of the public-API leg uses the same one (a second
+    # context would be a second set of nine streams competing for the 16 hardware queues)
+    ctx = _lib.default_context(local_rank)
     comm = parallel.connect(ctx, transport="file" if rehearse else None)
     comm_ranks = comm.info()[0]     # what RCCL reports (ncclCommCount) when the transport is RCCL
     ctx.set_moran_source_bits(args.source_bits)
@@ -453,7 +455,9 @@ def main() -> None:
                                       + (" [file transport, rehearsal]" if rehearse else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": perm_launches,
+                         "kernel": kernel_name, "kernel_forms": "k_moran_score_wg (chunks of 128 permutations) + k_moran_score "
+                                                                "(the pipeline's short first / last chunk); same arithmetic",
+                         "avg_launch_ms": avg_ms, "launches": perm_launches,
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "step_frac": rf["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step_frac_basis": "the same compulsory bytes of one step / ms_per_step / peak: what the whole "

@@ -174,6 +174,15 @@ int sc_moran(sc_ctx *ctx, int64_t n_perm, double *I_out, double *sims_out, int64
  * Fisher-Yates transpositions in ascending order; the rows themselves are materialised when a later call needs them). */
 int sc_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
                     int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out);
+/* sc_moran_seeded in two halves: _begin needs nothing but n_cells and the generator state and returns at once with the
+ * whole generator job enqueued, so the longest chain of the call runs while the caller builds the graph and uploads the
+ * expression (the reference's call order -- sq.gr.spatial_neighbors AC:565-570, then the matrix AC:573, then
+ * spatial_autocorr AC:576-583 -- put 60 ms of graph + PCIe work in front of it); _finish prepares the operands and
+ * scores chunk after chunk.  Same results and final state6 as sc_moran_seeded; _abort drops a begun job. */
+int sc_moran_seeded_begin(sc_ctx *ctx, const uint64_t *state6, int64_t n_cells, int64_t n_perm);
+int sc_moran_seeded_finish(sc_ctx *ctx, uint64_t *state6, double *I_out, double *sims_out, int64_t *count_ge_out,
+                           double *sim_sum_out, double *sim_sumsq_out);
+int sc_moran_seeded_abort(sc_ctx *ctx);
 
 /* ---- A8: Lee's L ---------------------------------------------------------------------------
  * Replaces _compute_lees_l_core (AC:307-332) for a list of (x, y) pairs over the loaded genes.

@@ -55,11 +55,15 @@ def main() -> None:
         for cname, acc in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
             for k, (nd, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
                 w.writerow([cname, k, nd, tot, tot / nd])
-    fk = [k for k in fetch if k.split("<")[0] == kernel]
+    # every form of the kernel (k_moran_score_wg for full chunks, k_moran_score for the pipeline's short first / last
+    # chunk): bench.py's roofline averages over all scoring launches of a step, so does this
+    fk = [k for k in fetch if k.split("<")[0].startswith(kernel)]
     if not fk:
         raise SystemExit(f"kernel {kernel} not in {fetch_dir}: {sorted(fetch)[:20]}")
-    nd, ftot = fetch[fk[0]]
-    wd, wtot = write.get(fk[0], [nd, 0.0])
+    nd = sum(fetch[k][0] for k in fk)
+    ftot = sum(fetch[k][1] for k in fk)
+    wd = sum(write.get(k, [0, 0.0])[0] for k in fk) or nd
+    wtot = sum(write.get(k, [0, 0.0])[1] for k in fk)
     f_kib = ftot / nd
     w_kib = wtot / max(wd, 1)
     hbm = (f_kib * (2.0 if double_fetch else 1.0) + w_kib) * 1024.0
@@ -68,6 +72,7 @@ def main() -> None:
 
     res = {
         "kernel": kernel,
+        "kernel_forms": sorted(fk),
         "source_hash": _lib.source_hash(),
         "cells": cells,
         "perms": perms,

@@ -57,6 +57,9 @@ SYMBOLS = {
     "sc_perm_counter_host": [ctypes.c_uint64, c_int64, c_int64, c_int64, _P],
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
+    "sc_moran_seeded_begin": [_P, _P, c_int64, c_int64],
+    "sc_moran_seeded_finish": [_P, _P, _P, _P, _P, _P, _P],
+    "sc_moran_seeded_abort": [_P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_lee_seeded": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
     "sc_lee_shared": [_P, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P, _P],
@@ -397,6 +400,28 @@ class Context:
         ssq = np.zeros(G, dtype=np.float64)
         _check(self._lib.sc_moran_seeded(self._h, _ptr(words), int(n_perm), _ptr(I), _ptr(sims), _ptr(cnt),
                                          _ptr(ssum), _ptr(ssq)))
+        self.permgen_note()
+        return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
+
+    def moran_seeded_begin(self, words: np.ndarray, n_cells: int, n_perm: int) -> None:
+        """First half of moran_seeded: the whole generator job is enqueued (it needs only n_cells and the state) and
+        runs while the caller builds the graph and uploads the expression; moran_seeded_finish scores."""
+        _check(self._lib.sc_moran_seeded_begin(self._h, _ptr(words), int(n_cells), int(n_perm)))
+        self._begun_perms = int(n_perm)
+
+    def moran_seeded_abort(self) -> None:
+        _check(self._lib.sc_moran_seeded_abort(self._h))
+        self._begun_perms = 0
+
+    def moran_seeded_finish(self, words: np.ndarray, return_sims: bool = True):
+        n_perm, G = self._begun_perms, self._n_genes
+        I = np.empty(G, dtype=np.float64)
+        sims = np.empty((n_perm, G), dtype=np.float64) if return_sims else None
+        cnt = np.zeros(G, dtype=np.int64)
+        ssum = np.zeros(G, dtype=np.float64)
+        ssq = np.zeros(G, dtype=np.float64)
+        self._begun_perms = 0
+        _check(self._lib.sc_moran_seeded_finish(self._h, _ptr(words), _ptr(I), _ptr(sims), _ptr(cnt), _ptr(ssum), _ptr(ssq)))
         self.permgen_note()
         return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
 

@@ -157,6 +157,7 @@ int sc_ctx_destroy(sc_ctx *c)
 {
     if (!c) return SC_OK;
     (void)hipSetDevice(c->device);
+    sc_perm_pipe_abort(c);
     (void)hipStreamSynchronize(c->stream);
     DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,
                     &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->knn_hd, &c->knn_hi, &c->rad_indptr,

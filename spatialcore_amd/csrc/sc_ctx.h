@@ -58,8 +58,11 @@ struct KTimer {
     int64_t launches = 0;
 };
 
+struct PermPipe;   // a generator job in flight (sc_moran.hip: sc_moran_seeded_begin .. _finish)
+
 struct sc_ctx {
     int device = 0;
+    PermPipe *pipe = nullptr;        // the generator / consumer pipeline begun by sc_moran_seeded_begin, until _finish
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // fused permutation/Moran pipeline: rejection scan runs ahead here
     hipStream_t stream3 = nullptr;  // ... and the Fisher-Yates swaps of the scanned chunk here
@@ -184,6 +187,16 @@ struct PermJob {
     int64_t unit_no = 0;
     int ahead = 1;             // units prepared ahead of the chain
 };
+// A generator job whose chunks are (being) enqueued on the generator's streams while the consumer catches up.
+struct PermPipe {
+    PermJob job;
+    std::vector<int64_t> bounds;       // chunk k = permutations [bounds[k], bounds[k + 1])
+    std::vector<hipEvent_t> ev;        // per chunk: scanned, swapped
+    int table = 0;                     // 0 rows, 1 inverse rows only, 2 both
+    int64_t n = 0, n_perm = 0, enqueued = 0;   // generator chunks enqueued so far
+    uint64_t state0[6] = {};           // the generator state the job started from (a sequential rerun starts there again)
+};
+void sc_perm_pipe_abort(sc_ctx *c);    // drain and drop c->pipe (no results)
 #define SC_PERMGEN_RETRY 1000  // internal: the block-parallel scan failed its verification, rerun sequentially
 bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);

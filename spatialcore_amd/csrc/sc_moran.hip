@@ -1240,8 +1240,9 @@ static int invert_rows(sc_ctx *c, int64_t p0, int64_t p1, hipStream_t s)
     const int rows = (int)(p1 - p0);
     if (rows <= 0) return SC_OK;
     const int groups = (rows + 7) / 8;
+    // (the table's own length, not the expression's: a generator job may run before any expression is loaded)
     hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(groups * INV_BLOCKS_PER_ROW * 8)), dim3(256), 0, s,
-                       c->perm.as<int32_t>() + p0 * c->p_stride, c->inv.as<int32_t>() + p0 * c->p_stride, c->e_n,
+                       c->perm.as<int32_t>() + p0 * c->p_stride, c->inv.as<int32_t>() + p0 * c->p_stride, c->p_n,
                        c->p_stride, rows);
     SC_HIP(hipGetLastError());
     return SC_OK;
@@ -1276,7 +1277,7 @@ static int moran_table_is_bijective(sc_ctx *c, int64_t n_perm, bool *bijective)
         SC_TRY(c->perm_flag.ensure(sizeof(unsigned long long), &c->mem));
         SC_HIP(hipMemsetAsync(c->perm_flag.p, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_check_inverse, dim3(2048), dim3(256), 0, c->stream, c->perm.as<int32_t>(),
-                           c->inv.as<int32_t>(), c->e_n, c->p_stride, rows, c->perm_flag.as<int>());
+                           c->inv.as<int32_t>(), c->p_n, c->p_stride, rows, c->perm_flag.as<int>());
         int bad = 0;
         SC_HIP(hipMemcpyAsync(&bad, c->perm_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         SC_HIP(hipStreamSynchronize(c->stream));
@@ -1447,7 +1448,7 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
 #define PIPE_FIRST 32        // permutations of the first pipeline chunk
 #endif
 #ifndef PIPE_LAST
-#define PIPE_LAST 64         // ... of the last one (0: none in particular)
+#define PIPE_LAST 48         // ... of the last one (0: none in particular)
 #endif
 #ifndef PIPE_SWAP_STREAMS
 #define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
@@ -1474,8 +1475,38 @@ static int64_t pipe_last_perms()
 // 1 = inverse rows only (c->inv; the same transpositions in ascending order), 2 = both (rows + k_invert_perm).
 // `after_first` runs on the host right after the first chunk of the generator has been enqueued (the generator is
 // the longest chain and depends on nothing else; everything host-blocking of the consumer's set-up goes here).
-int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int table,
-                     const std::function<int()> &after_first, const std::function<int(int64_t, int64_t)> &score)
+static int pipe_generate(sc_ctx *c, PermPipe &pp, int64_t k)
+{
+    hipEvent_t &scanned = pp.ev[(size_t)(2 * k)], &swapped = pp.ev[(size_t)(2 * k + 1)];
+    hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
+    SC_HIP(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
+    SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
+    SC_TRY(permgen_scan_chunk(c, &pp.job, pp.bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
+    SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
+    SC_TRY(permgen_swap_chunk(c, &pp.job, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw, pp.table == 1));
+    if (pp.table == 2) SC_TRY(invert_rows(c, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw));
+    SC_HIP(hipEventRecord(swapped, sw));
+    pp.enqueued = k + 1;
+    return SC_OK;
+}
+
+static void pipe_drain(sc_ctx *c, PermPipe &pp)
+{
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+    if (c->stream_px) (void)hipStreamSynchronize(c->stream_px);
+    for (hipStream_t sp : c->stream_pg)
+        if (sp) (void)hipStreamSynchronize(sp);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : pp.ev)
+        if (e) (void)hipEventDestroy(e);
+    pp.ev.clear();
+}
+
+// Begin: allocations, chunk schedule, the generator's set-up and its first `ahead` chunks (all of them when ahead
+// >= the number of chunks).  Needs nothing but n and the generator state -- no graph, no expression.
+static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, int table, PermPipe &pp, int64_t ahead)
 {
     SC_REQUIRE(state6, SC_ERR_INVALID, "permutation pipeline: null generator state");
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "permutation pipeline: n_perm must be >= 1");
@@ -1497,72 +1528,79 @@ int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int
     if (table >= 1) SC_TRY(c->inv.ensure(sizeof(int32_t) * (size_t)(c->p_stride * n_perm + 32), &c->mem));
     // chunk schedule: a short first chunk so that the consumer starts early, PERM_CHUNK each in the middle, a short
     // last chunk (the job ends with the swaps and the consumption of the last chunk after the scan is done)
-    std::vector<int64_t> bounds;
-    bounds.push_back(0);
+    pp.bounds.clear();
+    pp.bounds.push_back(0);
     if (n_perm > 3 * PERM_CHUNK) {
         const int64_t first = pipe_first_perms(), last = pipe_last_perms();
         const int64_t rest = (n_perm - last - first) % PERM_CHUNK;
         int64_t p = first + (rest < PERM_CHUNK / 2 ? rest : 0);  // a small remainder joins the first chunk
-        bounds.push_back(p);
-        if (rest >= PERM_CHUNK / 2) { p += rest; bounds.push_back(p); }
-        for (; p < n_perm - last; ) { p += PERM_CHUNK; bounds.push_back(p); }
-        if (last > 0) bounds.push_back(n_perm);
+        pp.bounds.push_back(p);
+        if (rest >= PERM_CHUNK / 2) { p += rest; pp.bounds.push_back(p); }
+        for (; p < n_perm - last; ) { p += PERM_CHUNK; pp.bounds.push_back(p); }
+        if (last > 0) pp.bounds.push_back(n_perm);
     } else {
-        for (int64_t p = PERM_CHUNK; p < n_perm; p += PERM_CHUNK) bounds.push_back(p);
-        bounds.push_back(n_perm);
+        for (int64_t p = PERM_CHUNK; p < n_perm; p += PERM_CHUNK) pp.bounds.push_back(p);
+        pp.bounds.push_back(n_perm);
     }
-    const int64_t chunks = (int64_t)bounds.size() - 1;
+    const int64_t chunks = (int64_t)pp.bounds.size() - 1;
     // stream2: scan(0) scan(1) ...   stream3/4: swaps(k) (+ inverse(k)) after scan(k)   stream: score(k) after swaps(k)
-    std::vector<hipEvent_t> ev((size_t)chunks * 2, nullptr);
-    PermJob job;
-    auto generate = [&](int64_t k) -> int {
-        hipEvent_t &scanned = ev[(size_t)(2 * k)], &swapped = ev[(size_t)(2 * k + 1)];
-        hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
-        SC_HIP(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
-        SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
-        SC_TRY(permgen_scan_chunk(c, &job, bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
-        SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
-        SC_TRY(permgen_swap_chunk(c, &job, bounds[(size_t)k], bounds[(size_t)k + 1], sw, table == 1));
-        if (table == 2) SC_TRY(invert_rows(c, bounds[(size_t)k], bounds[(size_t)k + 1], sw));
-        SC_HIP(hipEventRecord(swapped, sw));
-        return SC_OK;
-    };
-    int rc = permgen_begin(c, state6, n, n_perm, &job, c->stream2);
-    // The generator is the longest chain of the job and depends on nothing else: its chunks are enqueued TWO ahead of
-    // the consumption (chunks 0 and 1 before the consumer's host-blocking set-up, which waits for the graph and the
-    // expression statistics; r03 timeline: the chain sat idle for 5 ms behind that set-up with one chunk ahead), so
-    // that neither side waits for the host to enqueue the other (a chunk is some 250 API calls)
-    if (rc == SC_OK) rc = generate(0);
-    if (rc == SC_OK && chunks > 1) rc = generate(1);
-    if (rc == SC_OK && after_first) rc = after_first();
+    pp.ev.assign((size_t)chunks * 2, nullptr);
+    pp.table = table; pp.n = n; pp.n_perm = n_perm; pp.enqueued = 0;
+    for (int k = 0; k < 6; ++k) pp.state0[k] = state6[k];
+    pp.job = PermJob();
+    int rc = permgen_begin(c, state6, n, n_perm, &pp.job, c->stream2);
+    for (int64_t k = 0; k < chunks && k < ahead && rc == SC_OK; ++k) rc = pipe_generate(c, pp, k);
+    if (rc != SC_OK) pipe_drain(c, pp);
+    return rc;
+}
+
+// Consume: `after_first` (the consumer's host-blocking set-up) runs once, then `score(p0, p1)` behind every chunk's
+// swaps on the context stream, with the generator kept TWO chunks ahead in the host's enqueue order (r03 timeline: with
+// one chunk ahead the chain sat idle for 5 ms behind the consumer's set-up; a chunk is some 250 API calls).
+static int pipe_consume(sc_ctx *c, PermPipe &pp, uint64_t *state6, const std::function<int()> &after_first,
+                        const std::function<int(int64_t, int64_t)> &score)
+{
+    const int64_t chunks = (int64_t)pp.bounds.size() - 1;
+    int rc = SC_OK;
+    if (after_first) rc = after_first();
     c->perm_bijective = true;  // device-generated rows are permutations by construction
-    c->perm_forward_valid = table != 1;
+    c->perm_forward_valid = pp.table != 1;
     for (int64_t k = 0; k < chunks && rc == SC_OK; ++k) {
-        if (k + 2 < chunks) rc = generate(k + 2);
-        if (rc == SC_OK && hipStreamWaitEvent(c->stream, ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
+        while (rc == SC_OK && pp.enqueued < chunks && pp.enqueued < k + 3) rc = pipe_generate(c, pp, pp.enqueued);
+        if (rc == SC_OK && hipStreamWaitEvent(c->stream, pp.ev[(size_t)(2 * k + 1)], 0) != hipSuccess) {
             sc_set_error("permutation pipeline: event plumbing failed");
             rc = SC_ERR_HIP;
         }
-        if (rc == SC_OK) rc = score(bounds[(size_t)k], bounds[(size_t)k + 1]);
+        if (rc == SC_OK) rc = score(pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1]);
     }
-    (void)hipStreamSynchronize(c->stream2);
-    (void)hipStreamSynchronize(c->stream3);
-    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
-    if (c->stream_px) (void)hipStreamSynchronize(c->stream_px);
-    for (hipStream_t sp : c->stream_pg)
-        if (sp) (void)hipStreamSynchronize(sp);
-    (void)hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : ev)
-        if (e) (void)hipEventDestroy(e);
+    pipe_drain(c, pp);
     if (rc != SC_OK) return rc;
-    SC_TRY(permgen_finish(c, &job, state6));
-    c->p_count = n_perm;
-    c->inv_rows_valid = table >= 1 ? n_perm : 0;
+    SC_TRY(permgen_finish(c, &pp.job, state6));
+    c->p_count = pp.n_perm;
+    c->inv_rows_valid = pp.table >= 1 ? pp.n_perm : 0;
     return SC_OK;
 }
 
+void sc_perm_pipe_abort(sc_ctx *c)
+{
+    if (!c->pipe) return;
+    pipe_drain(c, *c->pipe);
+    delete c->pipe;
+    c->pipe = nullptr;
+    c->p_count = 0;
+}
+
+int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int table,
+                     const std::function<int()> &after_first, const std::function<int(int64_t, int64_t)> &score)
+{
+    sc_perm_pipe_abort(c);   // (a job begun with sc_moran_seeded_begin and never finished)
+    PermPipe pp;
+    SC_TRY(pipe_begin(c, state6, n, n_perm, table, pp, 2));
+    return pipe_consume(c, pp, state6, after_first, score);
+}
+
 static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
-                             int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+                             int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out, PermPipe *begun)
 {
     SC_REQUIRE(state6, SC_ERR_INVALID, "sc_moran_seeded: null state");
     SC_TRY(moran_check(c, n_perm, I_out));
@@ -1594,12 +1632,13 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         c->score_leave_cus = keep;
         return rc;
     };
-    SC_TRY(sc_perm_pipeline(c, state6, n, n_perm, inverse_only ? 1 : 2, prepare, score));
+    if (begun) SC_TRY(pipe_consume(c, *begun, state6, prepare, score));   // the generator has been running since _begin
+    else SC_TRY(sc_perm_pipeline(c, state6, n, n_perm, inverse_only ? 1 : 2, prepare, score));
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
 #ifndef SCORE_RESERVED_CUS
-#define SCORE_RESERVED_CUS 64
+#define SCORE_RESERVED_CUS 96
 #endif
 // SCORE_RESERVED_CUS: compute units the persistent scoring kernel leaves EMPTY for the generator that runs beside it.
 //
@@ -1613,8 +1652,12 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
 // launches).  With the uint8 source and the flag-ordered generator (one chain launch per chunk; its gate / publish
 // launches need free wavefront slots at once): 32 -> 2050, 40 / 48 -> 2177, 64 -> 2327, 72 -> 2332, 80 -> 2302,
 // 96 -> 2347, 128 -> 2173 (scoring 125 ms on 224 CUs, 157 on 192, 190 on 128: the step is balanced around 64-96).
+// r03, workgroup-shared lag rows (scoring a third faster, the step generator-bound): the chain itself slows down when
+// the scoring kernel has more of the chip -- chain busy 170 / 144 / 136 / 134 / 132 ms per step with 48 / 64 / 96 / 128 /
+// 160 CUs reserved (memory-system interference: the chain is one workgroup of dependent loads) -- and the step is
+// 198 / 179 / 175 / 180 / 196 ms: 96 (with a 48-permutation last chunk).
 static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, double *I_out, double *sims_out,
-                                int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out)
+                                int64_t *count_ge_out, double *sim_sum_out, double *sim_sumsq_out, PermPipe *begun = nullptr)
 {
     const int ahead = c->pg_ahead;
     int leave = c && c->e_n > 0 && permgen_is_block_parallel(c, c->e_n) ? SCORE_RESERVED_CUS : 8;
@@ -1622,7 +1665,7 @@ static int moran_seeded_streams(sc_ctx *c, uint64_t *state6, int64_t n_perm, dou
     c->pg_ahead = PIPE_AHEAD;
     if (const char *v = getenv("SC_PIPE_AHEAD")) c->pg_ahead = atoi(v);  // development: sweep the lookahead
     c->score_leave_cus = leave;
-    const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+    const int rc = moran_seeded_once(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out, begun);
     c->score_leave_cus = 0;
     c->pg_ahead = ahead;
     return rc;
@@ -1634,6 +1677,68 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
     SC_REQUIRE(c, SC_ERR_INVALID, "sc_moran_seeded: null context");
     int rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
     if (rc == SC_PERMGEN_RETRY) {  // the block-parallel scan failed its verification: nothing was returned yet
+        const int mode = c->pg_mode;
+        c->pg_mode = 1;
+        rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
+        c->pg_mode = mode;
+    }
+    return rc;
+}
+
+// The same call in two halves, so that the generator -- the longest chain of the job, which needs nothing but n_cells and
+// the seed's state -- runs while the caller is still building the graph and uploading the expression matrix
+// (morans_i: kNN + the D2H of the neighbour lists for obsp + 40 ms of PCIe upload used to sit in front of it):
+//   sc_moran_seeded_begin(ctx, state6, n_cells, n_perm)   enqueues the whole generator job and returns at once;
+//   ... sc_knn_2d / sc_graph_* / sc_expr_set_* on the same context ...
+//   sc_moran_seeded_finish(ctx, state6, outputs)          prepares the operands and scores chunk after chunk.
+// Results and the final generator state are those of sc_moran_seeded.  A job that is begun and not finished is
+// dropped by sc_moran_seeded_abort, by any call that replaces the permutation table, and with the context.
+extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t n_cells, int64_t n_perm)
+{
+    SC_REQUIRE(c && state6, SC_ERR_INVALID, "sc_moran_seeded_begin: null pointer");
+    SC_REQUIRE(n_perm >= 1 && n_perm <= (1 << 24), SC_ERR_INVALID, "sc_moran_seeded_begin: n_perm=%lld out of range", (long long)n_perm);
+    SC_HIP(hipSetDevice(c->device));
+    sc_perm_pipe_abort(c);
+    const int ahead = c->pg_ahead;
+    c->pg_ahead = PIPE_AHEAD;
+    if (const char *v = getenv("SC_PIPE_AHEAD")) c->pg_ahead = atoi(v);
+    PermPipe *pp = new PermPipe;
+    const int rc = pipe_begin(c, state6, n_cells, n_perm, permgen_can_swap_inverse(n_cells) ? 1 : 2, *pp, (int64_t)1 << 40);
+    c->pg_ahead = ahead;
+    if (rc != SC_OK) { delete pp; return rc; }
+    c->pipe = pp;
+    return SC_OK;
+}
+
+extern "C" int sc_moran_seeded_abort(sc_ctx *c)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipSetDevice(c->device));
+    sc_perm_pipe_abort(c);
+    return SC_OK;
+}
+
+extern "C" int sc_moran_seeded_finish(sc_ctx *c, uint64_t *state6, double *I_out, double *sims_out, int64_t *count_ge_out,
+                                      double *sim_sum_out, double *sim_sumsq_out)
+{
+    SC_REQUIRE(c && state6, SC_ERR_INVALID, "sc_moran_seeded_finish: null pointer");
+    SC_REQUIRE(c->pipe, SC_ERR_STATE, "sc_moran_seeded_finish: no job begun (sc_moran_seeded_begin)");
+    SC_HIP(hipSetDevice(c->device));
+    PermPipe *pp = c->pipe;
+    const int64_t n_perm = pp->n_perm;
+    int rc = SC_OK;
+    if (pp->n != c->e_n) {
+        sc_set_error("sc_moran_seeded_finish: the job was begun for %lld cells, the expression has %lld", (long long)pp->n, (long long)c->e_n);
+        rc = SC_ERR_INVALID;
+    }
+    if (rc == SC_OK) rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out, pp);
+    uint64_t state0[6];
+    for (int k = 0; k < 6; ++k) state0[k] = pp->state0[k];
+    c->pipe = nullptr;
+    pipe_drain(c, *pp);       // (no-op after a completed consume; an error path may have left launches in flight)
+    delete pp;
+    if (rc == SC_PERMGEN_RETRY) {  // the block-parallel scan failed its verification: nothing was returned, rerun in one piece
+        for (int k = 0; k < 6; ++k) state6[k] = state0[k];
         const int mode = c->pg_mode;
         c->pg_mode = 1;
         rc = moran_seeded_streams(c, state6, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);

@@ -124,6 +124,7 @@ int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm)
 {
     SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL, SC_ERR_INVALID, "permutation length %lld out of range", (long long)n);
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "n_perm must be >= 1");
+    sc_perm_pipe_abort(c);   // a generator job begun with sc_moran_seeded_begin and never finished owns the table
     int64_t stride = align_up64(n, 32);
     // +32 elements of slack so that the 8-wide tail reads of the last row stay inside the buffer
     SC_TRY(c->perm.ensure(sizeof(int32_t) * (size_t)(stride * n_perm + 32), &c->mem));

@@ -757,13 +757,13 @@ __global__ void k_gate(const uint32_t *flags, uint32_t chain_units_needed, unsig
 // ONCE per context, before the first block-parallel job, instead of finding out through a one-second give-up inside a
 // job: in five rounds each stream in turn hosts a setter kernel that is enqueued LAST, behind waiters on the other four;
 // two streams that share a queue deadlock in the round where the waiter of the pair sits in front of the setter, and
-// that waiter gives up after 5 ms.
+// that waiter gives up after 20 ms.
 __global__ void k_probe_wait(const uint32_t *flag, uint32_t want, uint32_t *timed_out)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (wall_clock64() - t0 > 500000ll) { atomicOr(timed_out, 1u); return; }   // 5 ms
+        if (wall_clock64() - t0 > 2000000ll) { atomicOr(timed_out, 1u); return; }   // 20 ms
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -780,6 +780,10 @@ static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
     uint32_t *words = c->perm_flag.as<uint32_t>();
     SC_HIP(hipDeviceSynchronize());
     SC_HIP(hipMemset(words, 0, 2 * sizeof(uint32_t)));
+    // a stream's hardware queue is created at its first launch, which takes milliseconds: warm every stream up first, or
+    // the waiters of round one give up before the setter's queue exists (seen with a second context in one process)
+    for (hipStream_t sp : ss) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sp, words, 0u, 0u);
+    for (hipStream_t sp : ss) SC_HIP(hipStreamSynchronize(sp));
     for (size_t setter = 0; setter < ss.size(); ++setter) {
         for (size_t k = 0; k < ss.size(); ++k)
             if (k != setter) hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, ss[k], words, (uint32_t)(setter + 1), words + 1);

@@ -245,14 +245,17 @@ def _moran_gene_batch(n_cells: int, requested: Optional[int]) -> int:
     return max(64, fit // 64 * 64)
 
 
-def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_table: bool = False) -> dict:
+def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_table: bool = False, begun=None) -> dict:
     """Global Moran's I on operands already resident on the device (graph + expression tiles):
     numpy-exact permutation table -> lag / permutation kernels -> p-value assembly as squidpy's
     ``_p_value_calc`` / ``_analytic_pval`` do [upstream].  Shared by ``morans_i`` and ``bench.py``.
     ``reuse_table``: score against the permutation table an earlier call with the same seed left on the device
-    (gene batches of one ``morans_i`` call share the table, as squidpy's permutations are shared by all genes)."""
+    (gene batches of one ``morans_i`` call share the table, as squidpy's permutations are shared by all genes).
+    ``begun``: the generator state words of a job already started with ``ctx.moran_seeded_begin``."""
     if n_permutations > 0 and reuse_table:
         out = ctx.moran(n_permutations, return_sims=False)
+    elif n_permutations > 0 and begun is not None:
+        out = ctx.moran_seeded_finish(begun, return_sims=False)
     elif n_permutations > 0:
         # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1.  Table generation and
         # scoring are pipelined on the device (sc_moran_seeded).
@@ -333,6 +336,25 @@ def morans_i(
                                "This indicates an internal error in squidpy or data corruption.")
 
     ctx = _lib.default_context(device)
+    # The permutation generator needs nothing but n_cells and the seed: it is started FIRST and runs on its own
+    # streams while the graph is built and the matrix crosses PCIe (squidpy: default_rng(seed + chunk index), one chunk
+    # when n_jobs=1); the scoring below joins it chunk by chunk.
+    begun = None
+    if n_permutations > 0 and len(gene_names) > 0:
+        begun = _lib.rng_state_words(np.random.default_rng(seed))
+        ctx.moran_seeded_begin(begun, n_cells, n_permutations)
+    try:
+        return _morans_i_on_device(adata, ctx, coords, gene_names, layer, n_neighbors, n_permutations, seed, key_added,
+                                   use_existing_graph, radius, gene_batch, begun, start_time)
+    except BaseException:
+        if begun is not None:
+            ctx.moran_seeded_abort()
+        raise
+
+
+def _morans_i_on_device(adata, ctx, coords, gene_names, layer, n_neighbors, n_permutations, seed, key_added,
+                        use_existing_graph, radius, gene_batch, begun, start_time):
+    n_cells, n_genes = adata.n_obs, len(gene_names)
     knn_found = None
     if use_existing_graph and "spatial_connectivities" in adata.obsp:
         logger.info("Using existing spatial connectivity graph (use_existing_graph=True)")
@@ -369,7 +391,7 @@ def morans_i(
             knn_found = None
         else:
             upload()
-        res = _moran_resident(ctx, n_cells, n_permutations, seed, reuse_table=b0 > 0)
+        res = _moran_resident(ctx, n_cells, n_permutations, seed, reuse_table=b0 > 0, begun=begun if b0 == 0 else None)
         score[b0:b0 + per_batch], p_all[b0:b0 + per_batch] = res["I"], res["p_value"]
     if knn_found is not None:   # (no gene batch ran)
         _record_squidpy_neighbors(adata, knn_found[0], knn_found[1], n_neighbors)

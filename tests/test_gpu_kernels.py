@@ -257,6 +257,52 @@ def test_moran_seeded_pipeline_equals_two_step(ctx, oracle, n, G, P):
     assert_counts_match(one["count_ge"], tab)
 
 
+@pytest.mark.parametrize("n,P", [(3000, 150), (140001, 300)])
+def test_moran_seeded_in_two_halves_equals_one_call(ctx, oracle, n, P):
+    """sc_moran_seeded_begin needs only n_cells and the generator state: the generator runs while the graph is built and
+    the expression uploaded; sc_moran_seeded_finish then gives exactly what the one-call form gives (statistics, counts,
+    final generator state), for the sequential and the block-parallel scan.  A begun job can be dropped."""
+    from spatialcore_amd._lib import SpatialCoreHipError, rng_state_words
+
+    G = 21
+    coords, X = synth(n, G, 12, dtype=np.float32, sparse_x=False)
+    ctx.knn(coords, 8, fetch=False)
+    ctx.graph_from_knn(1.0 / 8)
+    ctx.set_expression(X, np.arange(G))
+    w1 = rng_state_words(np.random.default_rng(5))
+    one = ctx.moran_seeded(w1, P)
+    from spatialcore_amd._lib import Context
+
+    with Context(0) as fresh:                                 # a context that has never seen a graph or an expression
+        w2 = rng_state_words(np.random.default_rng(5))
+        fresh.moran_seeded_begin(w2, n, P)                    # ... and only now the graph and the expression
+        fresh.knn(coords, 8, fetch=False)
+        fresh.graph_from_knn(1.0 / 8)
+        fresh.set_expression(X, np.arange(G))
+        two = fresh.moran_seeded_finish(w2)
+    np.testing.assert_array_equal(w1, w2)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    w2 = rng_state_words(np.random.default_rng(5))
+    ctx.moran_seeded_begin(w2, n, P)
+    ctx.moran_seeded_finish(w2)
+    again = ctx.moran(P)                                      # the table the job left is the resident table
+    np.testing.assert_array_equal(again["sims"], one["sims"])
+    with pytest.raises(SpatialCoreHipError, match="no job begun"):
+        ctx.moran_seeded_finish(w2)
+    w3 = rng_state_words(np.random.default_rng(6))
+    ctx.moran_seeded_begin(w3, n, P)
+    ctx.moran_seeded_abort()                                  # dropped: nothing returned, state untouched
+    np.testing.assert_array_equal(w3, rng_state_words(np.random.default_rng(6)))
+    ctx.moran_seeded_begin(w3, n, P)
+    w4 = rng_state_words(np.random.default_rng(5))
+    ctx.generate_permutations(w4, n, 3)                       # replaces the table: the begun job is dropped first
+    np.testing.assert_array_equal(ctx.moran(3)["sims"], one["sims"][:3])
+    ctx.moran_seeded_begin(w3, n + 1, 5)                      # begun for another cell count than the expression
+    with pytest.raises(ValueError, match="begun for"):
+        ctx.moran_seeded_finish(w3)
+
+
 @pytest.mark.parametrize("n,G,seed", [(5000, 70, 0), (4096, 33, 9)])
 def test_moran_seeded_bench_schedule_p1000_vs_oracle(ctx, oracle, n, G, seed):
     """The exact schedule bench.py runs: P = 1000 > 3 chunks switches sc_moran_seeded to the short-first /
