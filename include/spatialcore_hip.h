@@ -282,6 +282,12 @@ int sc_profile_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_t
  * observed counts.  Integer arithmetic, exact. */
 int sc_enrichment_counts(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types, int64_t n_perm,
                          int64_t perm_row0, int64_t *counts_out);
+/* The same test for ONE RANK'S RANGE [p_first, p_first + n_perm) of counter-based permutations (sc_perm_generate_counter's
+ * definition) in one call: batches of `batch` permutations are generated on a second stream beside the edge counting of
+ * the batch before, and only the integer sums come back -- observed_out[T*T]; sums_out[3][T*T] = sum_p (count_p - observed),
+ * sum_p (count_p - observed)^2, #{p : count_p >= observed}: exact and order-free, ranks add theirs (sc_allreduce_sum_i64). */
+int sc_enrichment_counter(sc_ctx *ctx, const int32_t *labels, int64_t n, int32_t n_types, uint64_t seed, int64_t p_first,
+                          int64_t n_perm, int64_t batch, int64_t *observed_out, int64_t *sums_out);
 
 /* ---- multi-GPU: the path's one collective -------------------------------
  * The reference is single-process (n_jobs=1 hard-coded at AC:580; no collective anywhere).  Here genes shard across

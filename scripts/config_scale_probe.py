@@ -1,7 +1,7 @@
 """At-size runs of the remaining BASELINE shapes through the public API (GPU box; not a test):
   local   local_morans_i, 1M cells x 100 genes x 999 permutations (N1) + lees_l_local, 2 pairs with per-cell p-values (N2)
   enrich  neighborhood_enrichment, 1M cells, k = 30, ~20 cell types, 10 000 label permutations (BASELINE configs[4])
-usage: python scripts/config_scale_probe.py local|enrich [n_perm]"""
+usage: python scripts/config_scale_probe.py local|enrich [n_perm] [numpy|philox]"""
 import json, logging, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
@@ -33,9 +33,13 @@ else:
     labels = rng.choice(20, N, p=w)
     ad = make_adata(coords, np.zeros((N, 1), dtype=np.float32), labels)
     sp.neighborhood_enrichment(ad, "cell_type", k=30, n_permutations=8)           # warm-up
-    t = time.perf_counter(); sp.neighborhood_enrichment(ad, "cell_type", k=30, n_permutations=P, seed=0); out["neighborhood_enrichment_s"] = time.perf_counter() - t
+    source = sys.argv[3] if len(sys.argv) > 3 else "numpy"
+    sp.neighborhood_enrichment(ad, "cell_type", k=30, n_permutations=600, seed=1, rng=source)  # warm-up at the batch size (allocations)
+    t = time.perf_counter(); sp.neighborhood_enrichment(ad, "cell_type", k=30, n_permutations=P, seed=0, rng=source); out["neighborhood_enrichment_s"] = time.perf_counter() - t
     r = ad.uns["neighborhood_enrichment"]
-    out["neighborhood_enrichment"] = f"k=30, {len(r['celltypes'])} cell types, {P} numpy-exact label permutations (one sequential stream: one GPU)"
+    out["neighborhood_enrichment"] = (f"k=30, {len(r['celltypes'])} cell types, {P} label permutations, rng={source} "
+                                      + ("(numpy-exact: one sequential stream, one GPU)" if source == "numpy"
+                                         else "(counter-based: Philox4x32-10 + Lemire, shardable over GPUs)"))
     out["zscore_diag_mean"] = float(np.nanmean(np.diag(r["zscore"])))
     out["permutations_per_s"] = P / out["neighborhood_enrichment_s"]
 out["permgen_stats"] = ctx.permgen_stats()

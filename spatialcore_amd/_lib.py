@@ -74,6 +74,7 @@ SYMBOLS = {
     "sc_pair_table_2d": [_P, _P, _P, c_int32, _P, _P, c_int32, _P, _P],
     "sc_profile_counts": [_P, _P, c_int64, c_int32, _P, POINTER(c_int64)],
     "sc_enrichment_counts": [_P, _P, c_int64, c_int32, c_int64, c_int64, _P],
+    "sc_enrichment_counter": [_P, _P, c_int64, c_int32, ctypes.c_uint64, c_int64, c_int64, c_int64, _P, _P],
     "sc_comm_unique_id": [_P],
     "sc_comm_create": [_P, _P, c_int, c_int, POINTER(c_void_p)],
     "sc_comm_destroy": [_P],
@@ -558,6 +559,17 @@ class Context:
         _check(self._lib.sc_enrichment_counts(self._h, _ptr(lab), lab.size, int(n_types), int(n_perm), int(perm_row0),
                                               _ptr(out)))
         return out
+
+
+    def enrichment_counter(self, labels, n_types: int, seed: int, p_first: int, n_perm: int, batch: int = 512):
+        """Observed T x T edge counts and the integer sums (deviation, squared deviation, exceedances) over the
+        counter-based label permutations p_first .. p_first + n_perm - 1, generation overlapped with counting."""
+        lab = _c(labels, np.int32)
+        obs = np.empty((n_types, n_types), dtype=np.int64)
+        sums = np.empty((3, n_types, n_types), dtype=np.int64)
+        _check(self._lib.sc_enrichment_counter(self._h, _ptr(lab), lab.size, int(n_types), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                               int(p_first), int(n_perm), int(batch), _ptr(obs), _ptr(sums)))
+        return obs, sums
 
 
 class RcclComm:

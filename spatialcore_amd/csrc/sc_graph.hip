@@ -1395,3 +1395,124 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The whole label-permutation test of one rank's range of counter-based permutations in ONE call (r03): the sums the
+// p-values and z-scores need are accumulated on the device, and the generation of batch b + 1 (stage B's swaps are
+// latency-bound: 21 ms per 512 permutations of 1M cells) runs on a second stream beside the edge counting of batch b
+// (37 ms per 512): the relabelled label vectors are the only thing the counting reads, so the table is free again as
+// soon as k_enrich_relabel is through.
+// ------------------------------------------------------------------------------------------------
+
+// sums[0][k] += sum_p (cnt_p[k] - obs[k]), sums[1][k] += sum_p (cnt_p[k] - obs[k])^2, sums[2][k] += #{p : cnt_p[k] >= obs[k]}
+__global__ __launch_bounds__(256) void k_enrich_sums(const unsigned long long *__restrict__ counts,
+                                                     const unsigned long long *__restrict__ obs, int n_perm, int tt,
+                                                     long long *__restrict__ sums)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= tt) return;
+    const long long o = (long long)obs[k];
+    long long s1 = 0, s2 = 0, ge = 0;
+    for (int p = 0; p < n_perm; ++p) {
+        const long long d = (long long)counts[(int64_t)p * tt + k] - o;
+        s1 += d;
+        s2 += d * d;
+        ge += d >= 0 ? 1 : 0;
+    }
+    sums[k] += s1;
+    sums[tt + k] += s2;
+    sums[2 * tt + k] += ge;
+}
+
+int sc_perm_counter_rows(sc_ctx *c, uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, hipStream_t s);   // sc_permgen.hip
+
+extern "C" int sc_enrichment_counter(sc_ctx *c, const int32_t *labels, int64_t n, int32_t n_types, uint64_t seed,
+                                     int64_t p_first, int64_t n_perm, int64_t batch, int64_t *observed_out, int64_t *sums_out)
+{
+    SC_REQUIRE(c && labels && observed_out && sums_out, SC_ERR_INVALID, "sc_enrichment_counter: null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->g_n > 0 && n == c->g_n, SC_ERR_STATE, "sc_enrichment_counter: graph missing or size mismatch");
+    SC_REQUIRE(n_types >= 1 && n_types <= 96, SC_ERR_INVALID, "sc_enrichment_counter: n_types must be 1..96");
+    SC_REQUIRE(n_perm >= 0 && p_first >= 0 && batch >= 1 && batch <= 65534, SC_ERR_INVALID, "sc_enrichment_counter: bad sizes");
+    SC_REQUIRE(ceil_div64(c->g_nnz, ENR_EDGES_PER_BLOCK) <= 65535, SC_ERR_INVALID, "sc_enrichment_counter: more than 4.2e9 edges");
+    std::vector<unsigned char> lab8((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        SC_REQUIRE(labels[i] >= 0 && labels[i] < n_types, SC_ERR_INVALID, "label %d of cell %lld out of range",
+                   labels[i], (long long)i);
+        lab8[(size_t)i] = (unsigned char)labels[i];
+    }
+    if (batch > n_perm) batch = n_perm > 0 ? n_perm : 1;
+    const int tt = n_types * n_types;
+    const int64_t lstride = align_up64(n, 16);
+    const size_t cnt_bytes = sizeof(unsigned long long) * (size_t)tt * (size_t)batch;
+    SC_TRY(c->lee_pairs.ensure((size_t)n + 16, &c->mem));
+    SC_TRY(c->lee_b.ensure(cnt_bytes + sizeof(unsigned long long) * (size_t)tt * 4, &c->mem));   // counts | observed | 3 sums
+    SC_TRY(c->lee_a.ensure((size_t)lstride * (size_t)batch, &c->mem));
+    unsigned long long *d_cnt = c->lee_b.as<unsigned long long>(), *d_obs = d_cnt + (size_t)tt * batch;
+    long long *d_sums = reinterpret_cast<long long *>(d_obs + tt);
+    SC_TRY(sc_graph_ensure_order(c));
+    if (n_perm > 0) SC_TRY(sc_perm_alloc(c, n, batch));
+    if (!c->stream3) SC_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    SC_HIP(hipMemcpyAsync(c->lee_pairs.p, lab8.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SC_HIP(hipMemsetAsync(d_obs, 0, sizeof(unsigned long long) * (size_t)tt * 4, c->stream));
+    int copies = 16;
+    const int cstride = tt | 1;   // odd: copy c starts at a different LDS bank
+    while (copies > 1 && (size_t)copies * cstride > 12288) copies >>= 1;   // <= 48 KB of LDS per workgroup
+    const unsigned eblocks = (unsigned)ceil_div64(c->g_nnz, ENR_EDGES_PER_BLOCK);
+    auto count = [&](int rows, const int32_t *table, unsigned long long *out) {
+        hipLaunchKernelGGL(k_enrich_relabel, dim3((unsigned)ceil_div64(n, 1024), (unsigned)rows), dim3(256), 0, c->stream,
+                           c->lee_pairs.as<unsigned char>(), c->g_order.as<int32_t>(), table, c->p_stride, table ? rows : 0, n,
+                           lstride, c->lee_a.as<unsigned char>());
+    };
+    auto edges = [&](int rows, unsigned long long *out) {
+        if (c->g_nnz > 0)
+            hipLaunchKernelGGL(k_enrich, dim3((unsigned)rows, eblocks), dim3(256), sizeof(unsigned int) * cstride * copies, c->stream,
+                               c->g_erow_r.as<int32_t>(), c->g_indices_r.as<int32_t>(), c->g_nnz, c->lee_a.as<unsigned char>(),
+                               lstride, (int)n_types, copies, cstride, out);
+    };
+    // observed labels: one "permutation" without a table
+    count(1, nullptr, d_obs);
+    edges(1, d_obs);
+    SC_HIP(hipGetLastError());
+    const int64_t batches = n_perm > 0 ? ceil_div64(n_perm, batch) : 0;
+    std::vector<hipEvent_t> ev((size_t)batches * 2, nullptr);
+    int rc = SC_OK;
+    auto generate = [&](int64_t b) -> int {   // batch b's rows into the table, on the generator's stream
+        const int64_t p0 = b * batch, cnt = p0 + batch < n_perm ? batch : n_perm - p0;
+        SC_TRY(sc_perm_counter_rows(c, seed, n, p_first + p0, cnt, c->stream3));
+        SC_HIP(hipEventCreateWithFlags(&ev[(size_t)(2 * b)], hipEventDisableTiming));
+        SC_HIP(hipEventRecord(ev[(size_t)(2 * b)], c->stream3));
+        return SC_OK;
+    };
+    if (batches > 0) {
+        SC_HIP(hipStreamSynchronize(c->stream));   // (the table may still be read by an earlier call's kernels)
+        rc = generate(0);
+    }
+    for (int64_t b = 0; b < batches && rc == SC_OK; ++b) {
+        const int64_t p0 = b * batch;
+        const int cnt = (int)(p0 + batch < n_perm ? batch : n_perm - p0);
+        if (hipStreamWaitEvent(c->stream, ev[(size_t)(2 * b)], 0) != hipSuccess) { rc = SC_ERR_HIP; break; }
+        count(cnt, c->perm.as<int32_t>(), d_cnt);
+        if (hipEventCreateWithFlags(&ev[(size_t)(2 * b + 1)], hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ev[(size_t)(2 * b + 1)], c->stream) != hipSuccess ||
+            hipStreamWaitEvent(c->stream3, ev[(size_t)(2 * b + 1)], 0) != hipSuccess) { rc = SC_ERR_HIP; break; }
+        if (b + 1 < batches) rc = generate(b + 1);   // beside the edge counting of batch b
+        if (rc != SC_OK) break;
+        if (hipMemsetAsync(d_cnt, 0, cnt_bytes, c->stream) != hipSuccess) { rc = SC_ERR_HIP; break; }
+        edges(cnt, d_cnt);
+        hipLaunchKernelGGL(k_enrich_sums, dim3((unsigned)ceil_div64(tt, 256)), dim3(256), 0, c->stream, d_cnt, d_obs, cnt, tt, d_sums);
+    }
+    if (rc == SC_ERR_HIP) sc_set_error("sc_enrichment_counter: event plumbing failed");
+    (void)hipStreamSynchronize(c->stream3);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (rc != SC_OK) return rc;
+    SC_HIP(hipGetLastError());
+    c->p_count = 0;   // the table holds the last batch only: not a table later calls may rely on
+    std::vector<unsigned long long> host((size_t)tt * 4);
+    SC_HIP(hipMemcpy(host.data(), d_obs, sizeof(unsigned long long) * (size_t)tt * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < tt; ++k) observed_out[k] = (int64_t)host[(size_t)k];
+    for (int k = 0; k < 3 * tt; ++k) sums_out[k] = (int64_t)host[(size_t)tt + k];
+    return SC_OK;
+}

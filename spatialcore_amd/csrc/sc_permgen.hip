@@ -1610,29 +1610,39 @@ extern "C" int sc_perm_counter_host(uint64_t seed, int64_t n, int64_t p_first, i
     return SC_OK;
 }
 
+// rows [0, n_perm) of the (already allocated, >= n_perm rows) table <- counter-based permutations p_first .., on stream s
+int sc_perm_counter_rows(sc_ctx *c, uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, hipStream_t s)
+{
+    if (n_perm <= 0) return SC_OK;
+    if (n == 1) {
+        SC_HIP(hipMemsetAsync(c->perm.p, 0, sizeof(int32_t) * (size_t)(c->p_stride * n_perm), s));
+        return SC_OK;
+    }
+    const int64_t M = n - 1;
+    SC_TRY(c->pg_J.ensure(sizeof(int32_t) * (size_t)(M * n_perm + 64), &c->mem));
+    const int64_t total = M * n_perm;
+    const unsigned grid = (unsigned)(ceil_div64(total, 256) < 65536 ? ceil_div64(total, 256) : 65536);
+    hipLaunchKernelGGL(k_counter_J, dim3(grid), dim3(256), 0, s, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)n,
+                       (uint64_t)p_first, n_perm, c->pg_J.as<int32_t>());
+    if (n >= SWAPS_WG_MIN_N)
+        hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)n_perm), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+                           c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
+    else
+        hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)n_perm), dim3(64), 0, s, c->pg_J.as<int32_t>(),
+                           c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 extern "C" int sc_perm_generate_counter(sc_ctx *c, uint64_t seed, int64_t n, int64_t p_first, int64_t n_perm, int32_t *perm_out)
 {
     SC_REQUIRE(c, SC_ERR_INVALID, "sc_perm_generate_counter: null context");
     SC_REQUIRE(p_first >= 0, SC_ERR_INVALID, "sc_perm_generate_counter: negative first permutation");
     SC_HIP(hipSetDevice(c->device));
     SC_TRY(sc_perm_alloc(c, n, n_perm));
-    if (n == 1) {
-        SC_HIP(hipMemsetAsync(c->perm.p, 0, sizeof(int32_t) * (size_t)(c->p_stride * n_perm), c->stream));
-    } else {
-        const int64_t M = n - 1;
-        SC_TRY(c->pg_J.ensure(sizeof(int32_t) * (size_t)(M * n_perm + 64), &c->mem));
+    {
         KernelTimerScope ts(c, SC_K_PERMGEN);
-        const int64_t total = M * n_perm;
-        const unsigned grid = (unsigned)(ceil_div64(total, 256) < 65536 ? ceil_div64(total, 256) : 65536);
-        hipLaunchKernelGGL(k_counter_J, dim3(grid), dim3(256), 0, c->stream, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)n,
-                           (uint64_t)p_first, n_perm, c->pg_J.as<int32_t>());
-        if (n >= SWAPS_WG_MIN_N)
-            hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)n_perm), dim3(SW_T), 0, c->stream, c->pg_J.as<int32_t>(),
-                               c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
-        else
-            hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)n_perm), dim3(64), 0, c->stream, c->pg_J.as<int32_t>(),
-                               c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
-        SC_HIP(hipGetLastError());
+        SC_TRY(sc_perm_counter_rows(c, seed, n, p_first, n_perm, c->stream));
     }
     c->p_count = n_perm;
     c->perm_bijective = true;

@@ -205,13 +205,15 @@ def neighborhood_enrichment(
     s2 = np.zeros((T, T), dtype=np.int64)
     ge = np.zeros((T, T), dtype=np.int64)
     done = lo
-    while True:
+    while rng == "philox":
+        # one device call for this rank's whole range: generation of batch b + 1 beside the edge counting of batch b,
+        # integer sums accumulated on the device
+        observed, (s1, s2, ge) = ctx.enrichment_counter(codes, T, seed, lo, hi - lo, perm_batch)
+        break
+    while rng == "numpy":
         batch = min(perm_batch, hi - done)
         if batch > 0:
-            if rng == "numpy":
-                ctx.generate_permutations(words, n_cells, batch)   # one stream, continued batch after batch
-            else:
-                ctx.generate_permutations_counter(seed, n_cells, batch, p_first=done)
+            ctx.generate_permutations(words, n_cells, batch)   # one stream, continued batch after batch
         cnt = ctx.enrichment_counts(codes, T, batch)
         observed = cnt[batch]
         dev = cnt[:batch] - observed
