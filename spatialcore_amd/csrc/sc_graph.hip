@@ -592,7 +592,10 @@ int sc_graph_capture_order(sc_ctx *c, int64_t n)
 {
     c->g_order_ready = false;
     SC_TRY(c->g_order.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
-    if (c->pts_n == n && c->px.p && c->py.p && c->bin_keys.p && c->bin_keys2.p && c->sid2.p) {
+    static const char *order_env = getenv("SC_GRAPH_ORDER");   // development A/B: "rowmajor" = r02's bin order
+    if (order_env && order_env[0] == 'r' && c->pts_n == n && c->sid.p) {
+        SC_HIP(hipMemcpyAsync(c->g_order.p, c->sid.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->pts_n == n && c->px.p && c->py.p && c->bin_keys.p && c->bin_keys2.p && c->sid2.p) {
         const double ext = (double)(c->nbx > c->nby ? c->nbx : c->nby) * c->gh;
         hipLaunchKernelGGL(k_morton_keys, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->px.as<double>(),
                            c->py.as<double>(), n, c->gx0, c->gy0, ext > 0.0 ? 1.0 / ext : 0.0, c->bin_keys.as<uint32_t>(),
@@ -1404,6 +1407,63 @@ extern "C" int sc_enrichment_counts(sc_ctx *c, const int32_t *labels, int64_t n,
 // soon as k_enrich_relabel is through.
 // ------------------------------------------------------------------------------------------------
 
+// ---- sixteen permutations per edge (r03) ------------------------------------------------------------------------------
+// k_enrich re-reads the 8 bytes of every edge once per permutation (123 GB of L2 traffic per 512 permutations of a 30M-edge
+// graph: what bounds it, 37 ms).  Here the permuted labels of SIXTEEN permutations of a cell are one 16-byte word (at the
+// cell's position in the graph's processing order), so an edge's indices are read once per 16 permutations and its two
+// label words bring 16 label pairs.  Each of the 16 permutations has its own T x T histogram in LDS; lane l handles them
+// in the rotated order (s + l) % 16, so that a wavefront's 64 atomics of one step spread over 16 histograms (what
+// k_enrich's 16 private copies did).
+#define ENR16_MAX_TT 768   // 16 histograms of <= 768 bins: 48 KB of LDS (T <= 27)
+
+// lab16[g][rank[cell]] = the labels of `cell` under permutations 16 g .. 16 g + 15 (rows clamped to rows - 1)
+__global__ __launch_bounds__(256) void k_enrich_relabel16(const unsigned char *__restrict__ lab, const int32_t *__restrict__ rank,
+                                                          const int32_t *__restrict__ perm, int64_t pstride, int rows, int64_t n,
+                                                          uint4 *__restrict__ lab16)
+{
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= n) return;
+    const int g = blockIdx.y;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int row = 16 * g + p < rows ? 16 * g + p : rows - 1;
+        w[p >> 2] |= (uint32_t)lab[perm[(int64_t)row * pstride + cell]] << (8 * (p & 3));
+    }
+    lab16[(int64_t)g * n + rank[cell]] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void k_enrich16(const int32_t *__restrict__ erow_r, const int32_t *__restrict__ ecol_r,
+                                                  int64_t nnz, const uint4 *__restrict__ lab16, int64_t n, int n_types,
+                                                  int hstride, int rows, unsigned long long *__restrict__ counts)
+{
+    extern __shared__ unsigned int hist[];   // [16][hstride]
+    const int g = blockIdx.x;
+    const int tt = n_types * n_types;
+    for (int k = threadIdx.x; k < 16 * hstride; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint4 *lp = lab16 + (int64_t)g * n;
+    const int rot = threadIdx.x & 15;
+    const int64_t e0 = (int64_t)blockIdx.y * ENR_EDGES_PER_BLOCK;
+    const int64_t e1 = e0 + ENR_EDGES_PER_BLOCK < nnz ? e0 + ENR_EDGES_PER_BLOCK : nnz;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const uint4 a = lp[erow_r[e]], b = lp[ecol_r[e]];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int p = (s + rot) & 15;
+            const uint32_t la = (aw[p >> 2] >> (8 * (p & 3))) & 0xffu, lb = (bw[p >> 2] >> (8 * (p & 3))) & 0xffu;
+            atomicAdd(&hist[p * hstride + (int)la * n_types + (int)lb], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 16 * tt; k += 256) {
+        const int p = k / tt, bin = k - p * tt;
+        const unsigned int v = hist[p * hstride + bin];
+        if (v && 16 * g + p < rows) atomicAdd(&counts[(int64_t)(16 * g + p) * tt + bin], (unsigned long long)v);
+    }
+}
+
 // sums[0][k] += sum_p (cnt_p[k] - obs[k]), sums[1][k] += sum_p (cnt_p[k] - obs[k])^2, sums[2][k] += #{p : cnt_p[k] >= obs[k]}
 __global__ __launch_bounds__(256) void k_enrich_sums(const unsigned long long *__restrict__ counts,
                                                      const unsigned long long *__restrict__ obs, int n_perm, int tt,
@@ -1447,7 +1507,7 @@ extern "C" int sc_enrichment_counter(sc_ctx *c, const int32_t *labels, int64_t n
     const size_t cnt_bytes = sizeof(unsigned long long) * (size_t)tt * (size_t)batch;
     SC_TRY(c->lee_pairs.ensure((size_t)n + 16, &c->mem));
     SC_TRY(c->lee_b.ensure(cnt_bytes + sizeof(unsigned long long) * (size_t)tt * 4, &c->mem));   // counts | observed | 3 sums
-    SC_TRY(c->lee_a.ensure((size_t)lstride * (size_t)batch, &c->mem));
+    SC_TRY(c->lee_a.ensure((size_t)lstride * (size_t)align_up64(batch, 16), &c->mem));   // (also the 16-wide form: n x 16 B per 16 rows)
     unsigned long long *d_cnt = c->lee_b.as<unsigned long long>(), *d_obs = d_cnt + (size_t)tt * batch;
     long long *d_sums = reinterpret_cast<long long *>(d_obs + tt);
     SC_TRY(sc_graph_ensure_order(c));
@@ -1459,20 +1519,32 @@ extern "C" int sc_enrichment_counter(sc_ctx *c, const int32_t *labels, int64_t n
     const int cstride = tt | 1;   // odd: copy c starts at a different LDS bank
     while (copies > 1 && (size_t)copies * cstride > 12288) copies >>= 1;   // <= 48 KB of LDS per workgroup
     const unsigned eblocks = (unsigned)ceil_div64(c->g_nnz, ENR_EDGES_PER_BLOCK);
+    const bool wide = tt <= ENR16_MAX_TT && !getenv("SC_ENRICH_NARROW");   // sixteen permutations per edge (k_enrich16)
+    const int hstride = tt | 1;
     auto count = [&](int rows, const int32_t *table, unsigned long long *out) {
-        hipLaunchKernelGGL(k_enrich_relabel, dim3((unsigned)ceil_div64(n, 1024), (unsigned)rows), dim3(256), 0, c->stream,
-                           c->lee_pairs.as<unsigned char>(), c->g_order.as<int32_t>(), table, c->p_stride, table ? rows : 0, n,
-                           lstride, c->lee_a.as<unsigned char>());
+        if (wide && table)
+            hipLaunchKernelGGL(k_enrich_relabel16, dim3((unsigned)ceil_div64(n, 256), (unsigned)((rows + 15) / 16)), dim3(256), 0,
+                               c->stream, c->lee_pairs.as<unsigned char>(), c->g_rank.as<int32_t>(), table, c->p_stride, rows, n,
+                               c->lee_a.as<uint4>());
+        else
+            hipLaunchKernelGGL(k_enrich_relabel, dim3((unsigned)ceil_div64(n, 1024), (unsigned)rows), dim3(256), 0, c->stream,
+                               c->lee_pairs.as<unsigned char>(), c->g_order.as<int32_t>(), table, c->p_stride, table ? rows : 0, n,
+                               lstride, c->lee_a.as<unsigned char>());
     };
-    auto edges = [&](int rows, unsigned long long *out) {
-        if (c->g_nnz > 0)
+    auto edges = [&](int rows, unsigned long long *out, bool from_table) {
+        if (c->g_nnz <= 0) return;
+        if (wide && from_table)
+            hipLaunchKernelGGL(k_enrich16, dim3((unsigned)((rows + 15) / 16), eblocks), dim3(256), sizeof(unsigned int) * 16 * hstride,
+                               c->stream, c->g_erow_r.as<int32_t>(), c->g_indices_r.as<int32_t>(), c->g_nnz, c->lee_a.as<uint4>(), n,
+                               (int)n_types, hstride, rows, out);
+        else
             hipLaunchKernelGGL(k_enrich, dim3((unsigned)rows, eblocks), dim3(256), sizeof(unsigned int) * cstride * copies, c->stream,
                                c->g_erow_r.as<int32_t>(), c->g_indices_r.as<int32_t>(), c->g_nnz, c->lee_a.as<unsigned char>(),
                                lstride, (int)n_types, copies, cstride, out);
     };
     // observed labels: one "permutation" without a table
     count(1, nullptr, d_obs);
-    edges(1, d_obs);
+    edges(1, d_obs, false);
     SC_HIP(hipGetLastError());
     const int64_t batches = n_perm > 0 ? ceil_div64(n_perm, batch) : 0;
     std::vector<hipEvent_t> ev((size_t)batches * 2, nullptr);
@@ -1499,7 +1571,7 @@ extern "C" int sc_enrichment_counter(sc_ctx *c, const int32_t *labels, int64_t n
         if (b + 1 < batches) rc = generate(b + 1);   // beside the edge counting of batch b
         if (rc != SC_OK) break;
         if (hipMemsetAsync(d_cnt, 0, cnt_bytes, c->stream) != hipSuccess) { rc = SC_ERR_HIP; break; }
-        edges(cnt, d_cnt);
+        edges(cnt, d_cnt, true);
         hipLaunchKernelGGL(k_enrich_sums, dim3((unsigned)ceil_div64(tt, 256)), dim3(256), 0, c->stream, d_cnt, d_obs, cnt, tt, d_sums);
     }
     if (rc == SC_ERR_HIP) sc_set_error("sc_enrichment_counter: event plumbing failed");

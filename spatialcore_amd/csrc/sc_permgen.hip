@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 
 #define PHI_W 16384               // window bits per side
 #define PHI_WORDS (PHI_W / 64)
+#ifndef PHI_MAX_EV
 #define PHI_MAX_EV 2048           // events per side a prepared block may hold
+#endif
 #ifndef PHI_WINDOW
 #define PHI_WINDOW 2.25           // window half-width in units of sqrt(draws since the reference state) (= 4.5 sigma)
 #endif

@@ -163,6 +163,10 @@ class FileComm:
             for r in range(self.world):
                 _await_file(os.path.join(self._dir, f"done_{r}"), self._timeout)
             shutil.rmtree(self._dir, ignore_errors=True)
+            try:
+                os.unlink(rendezvous_file(0) + ".turn")     # the rehearsal's GPU-turn lock file, if one was used
+            except OSError:
+                pass
 
 
 class device_turn:
