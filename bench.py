@@ -312,6 +312,11 @@ def main() -> None:
 
     def device_part():
         nonlocal mem_peak
+        # the order morans_i itself uses: the permutation generator (it needs only n and the seed, and it is the longest
+        # chain of the step) starts first; graph, moments and scoring join it
+        begun = _lib.rng_state_words(np.random.default_rng(args.seed)) if P > 0 else None
+        if begun is not None:
+            ctx.moran_seeded_begin(begun, n, P, ahead_chunks=2)
         ctx.knn(coords, k, fetch=False)
         ctx.graph_from_knn(1.0 / k)
         rows = []
@@ -320,7 +325,7 @@ def main() -> None:
             if len(batches) > 1:
                 ctx.set_expression(batch_matrix(bi)[:, : b1 - b0], np.arange(b1 - b0))   # upload inside the step
             if bi == 0:
-                res = _moran_resident(ctx, n, P, args.seed)                # generator + scoring, pipelined
+                res = _moran_resident(ctx, n, P, args.seed, begun=begun)   # generator + scoring, pipelined
             else:
                 res = _moran_resident(ctx, n, P, args.seed, reuse_table=True)   # the rank's resident table
             rows.append(np.stack([res["I"], res["p_value"]], axis=1))

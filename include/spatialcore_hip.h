@@ -178,8 +178,10 @@ int sc_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, double *I_out
  * whole generator job enqueued, so the longest chain of the call runs while the caller builds the graph and uploads the
  * expression (the reference's call order -- sq.gr.spatial_neighbors AC:565-570, then the matrix AC:573, then
  * spatial_autocorr AC:576-583 -- put 60 ms of graph + PCIe work in front of it); _finish prepares the operands and
- * scores chunk after chunk.  Same results and final state6 as sc_moran_seeded; _abort drops a begun job. */
-int sc_moran_seeded_begin(sc_ctx *ctx, const uint64_t *state6, int64_t n_cells, int64_t n_perm);
+ * scores chunk after chunk.  Same results and final state6 as sc_moran_seeded; _abort drops a begun job.
+ * ahead_chunks: generator chunks (of <= 128 permutations) enqueued before _begin returns: 0 = all (callers with an upload
+ * in front of _finish), n >= 2 = that many (each costs ~3.5 ms of host time; _finish enqueues the rest as it scores). */
+int sc_moran_seeded_begin(sc_ctx *ctx, const uint64_t *state6, int64_t n_cells, int64_t n_perm, int64_t ahead_chunks);
 int sc_moran_seeded_finish(sc_ctx *ctx, uint64_t *state6, double *I_out, double *sims_out, int64_t *count_ge_out,
                            double *sim_sum_out, double *sim_sumsq_out);
 int sc_moran_seeded_abort(sc_ctx *ctx);

@@ -57,7 +57,7 @@ SYMBOLS = {
     "sc_perm_counter_host": [ctypes.c_uint64, c_int64, c_int64, c_int64, _P],
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
-    "sc_moran_seeded_begin": [_P, _P, c_int64, c_int64],
+    "sc_moran_seeded_begin": [_P, _P, c_int64, c_int64, c_int64],
     "sc_moran_seeded_finish": [_P, _P, _P, _P, _P, _P, _P],
     "sc_moran_seeded_abort": [_P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
@@ -404,10 +404,11 @@ class Context:
         self.permgen_note()
         return {"I": I, "sims": sims, "count_ge": cnt, "sim_sum": ssum, "sim_sumsq": ssq}
 
-    def moran_seeded_begin(self, words: np.ndarray, n_cells: int, n_perm: int) -> None:
-        """First half of moran_seeded: the whole generator job is enqueued (it needs only n_cells and the state) and
-        runs while the caller builds the graph and uploads the expression; moran_seeded_finish scores."""
-        _check(self._lib.sc_moran_seeded_begin(self._h, _ptr(words), int(n_cells), int(n_perm)))
+    def moran_seeded_begin(self, words: np.ndarray, n_cells: int, n_perm: int, ahead_chunks: int = 0) -> None:
+        """First half of moran_seeded: the generator job (it needs only n_cells and the state) starts and runs while the
+        caller builds the graph and uploads the expression; moran_seeded_finish scores.  ahead_chunks: generator chunks
+        enqueued before this returns (0 = all: for callers with an upload in front of the finish; else >= 2)."""
+        _check(self._lib.sc_moran_seeded_begin(self._h, _ptr(words), int(n_cells), int(n_perm), int(ahead_chunks)))
         self._begun_perms = int(n_perm)
 
     def moran_seeded_abort(self) -> None:

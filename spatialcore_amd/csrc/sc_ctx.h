@@ -105,7 +105,7 @@ struct sc_ctx {
     int64_t g_deg_max = 0;      // longest row
     bool gt_valid = false;
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
-    bool s0_valid = false;
+    bool s0_valid = false, s0_only_valid = false;   // all three moments / s0 alone (k_weight_sum) are those of the active graph
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // graph moments (valid with s0_valid)
     // a processing order with spatial locality for kernels that read neighbours' rows (local Moran): the bin-sorted
     // order of the points the graph was built from (identity for a graph of unknown geometry).  Results never depend on it.

@@ -504,6 +504,7 @@ extern "C" int sc_radius_fill_2d(sc_ctx *c, int64_t nnz, int32_t *indices_out)
     c->g_nnz = 0;
     c->gt_valid = false;
     c->s0_valid = false;
+    c->s0_only_valid = false;
     return SC_OK;
 }
 
@@ -657,6 +658,7 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     c->g_n = 0;
     c->gt_valid = false;
     c->s0_valid = false;
+    c->s0_only_valid = false;
     SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
     SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
     SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
@@ -712,6 +714,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
     c->g_n = 0;
     c->gt_valid = false;
     c->s0_valid = false;
+    c->s0_only_valid = false;
     SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
     SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)nnz, &c->mem));
     SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)nnz, &c->mem));
@@ -914,11 +917,48 @@ extern "C" int sc_graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
     return graph_moments(c, s0, s1, s2);
 }
 
+// s0 alone -- all the scoring needs -- without the transpose and the reverse-edge search of the full moments (4.7 ms of the
+// step's serial prelude at bench size): the same per-row sums and the same reduction tree as k_moments' first partial,
+// so the value is bit-identical to graph_moments' s0.
+__global__ __launch_bounds__(256) void k_weight_sum(const long long *__restrict__ indptr, const double *__restrict__ data,
+                                                    int64_t n, double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    double a0 = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * MOM_ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + MOM_ROWS_PER_BLOCK < n ? r0 + MOM_ROWS_PER_BLOCK : n;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+        double rs = 0.0;
+        for (long long e = indptr[i]; e < indptr[i + 1]; ++e) rs += data[e];
+        a0 += rs;
+    }
+    sh[threadIdx.x] = a0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
 int sc_graph_ensure_s0(sc_ctx *c)
 {
-    if (c->s0_valid) return SC_OK;
-    double a, b, d;
-    return graph_moments(c, &a, &b, &d);
+    if (c->s0_valid || c->s0_only_valid) return SC_OK;
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    const int64_t n = c->g_n;
+    const int blocks = (int)ceil_div64(n, MOM_ROWS_PER_BLOCK);
+    SC_TRY(c->red_tmp.ensure(sizeof(double) * 3 * (size_t)blocks, &c->mem));
+    hipLaunchKernelGGL(k_weight_sum, dim3(blocks), dim3(256), 0, c->stream, c->g_indptr.as<long long>(), c->g_data.as<double>(), n,
+                       c->red_tmp.as<double>());
+    SC_HIP(hipGetLastError());
+    std::vector<double> h((size_t)blocks);
+    SC_HIP(hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    double a0 = 0;
+    for (int b = 0; b < blocks; ++b) a0 += h[(size_t)b];
+    c->s0 = a0;
+    c->s0_only_valid = true;
+    return SC_OK;
 }
 
 // y[i] = sum_e w[e] * x[col[e]]  for one contiguous vector

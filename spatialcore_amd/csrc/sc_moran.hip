@@ -1147,6 +1147,82 @@ static int moran_check(sc_ctx *c, int64_t n_perm, const double *I_out)
     return SC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The prelude of an all-lattice uint8 batch in one pass (r03).  For count data on a kNN graph the streamed operand of
+// the scoring kernel is S = A x, the unweighted neighbour sums of the raw counts.  k_lag makes them from fp64 tiles: 15
+// neighbours x 8 lanes x 16 B per cell and 16-gene tile = 61 GB through the CUs' texture path at bench size, 11.8 ms in
+// the scoring's serial prelude.  The uint8 rows the scoring kernel gathers hold 128 genes per 128 bytes: summing THOSE is
+// an eighth of the gathered bytes, the sums fit 16 bits (degree <= 257), and the two column sums the observed statistic
+// needs (T_obs = sum_i x_i S_i, sum_i S_i: integers, exact in fp64 in any order) fall out of the same pass.  Cells are
+// walked in the graph's processing order, one XCD per contiguous eighth.  Lag gets the same fp64 values k_lag writes
+// for lattice genes (integers), so everything downstream is bit-identical.
+// ------------------------------------------------------------------------------------------------
+#define LAG8_CELLS_PER_BLOCK 4096
+
+__global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                const uint4 *__restrict__ narrow, const int32_t *__restrict__ order, int64_t n,
+                                                int tiles16, int64_t tile_elems, double *__restrict__ Lag,
+                                                double *__restrict__ partial /* [2][tile][chunk][16] */, int chunks)
+{
+    __shared__ double shT[128], shS[128];      // [tile of the group][slot]
+    const int grp = blockIdx.y;
+    const int64_t per_xcd = (int64_t)(gridDim.x >> 3);
+    const int64_t chunk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // gridDim.x is a multiple of 8
+    const int q = threadIdx.x & 7, row = threadIdx.x >> 3;
+    if (threadIdx.x < 128) { shT[threadIdx.x] = 0.0; shS[threadIdx.x] = 0.0; }
+    __syncthreads();
+    const uint4 *Xg = narrow + (int64_t)grp * n * 8;
+    const int tiles_left = tiles16 - 8 * grp;
+    double accT[16], accS[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) accT[b] = accS[b] = 0.0;
+    const int64_t p0 = chunk * LAG8_CELLS_PER_BLOCK;
+    if (chunk < chunks) {
+        for (int it = 0; it < LAG8_CELLS_PER_BLOCK / 32; ++it) {
+            const int64_t pos = p0 + it * 32 + row;
+            if (pos >= n) break;
+            const int64_t cell = order ? order[pos] : pos;
+            const uint4 own = Xg[cell * 8 + q];
+            uint32_t lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};   // packed 16-bit sums of the even / odd bytes
+            for (long long e = indptr[cell]; e < indptr[cell + 1]; ++e) {
+                const uint4 v = Xg[(int64_t)indices[e] * 8 + q];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lo[k] += w[k] & 0x00ff00ffu; hi[k] += (w[k] >> 8) & 0x00ff00ffu; }
+            }
+            const uint32_t xo[4] = {own.x, own.y, own.z, own.w};
+            // byte b = 2 t + e of the lane's 16 bytes is gene 16 t + 2 q + e of the group: word t >> 1, byte 2 (t & 1) + e
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = t >> 1, sh = 16 * (t & 1);
+                const double s0 = (double)((lo[k] >> sh) & 0xffffu), s1 = (double)((hi[k] >> sh) & 0xffffu);
+                const double x0 = (double)((xo[k] >> sh) & 0xffu), x1 = (double)((xo[k] >> (sh + 8)) & 0xffu);
+                if (t < tiles_left)
+                    reinterpret_cast<double2 *>(Lag + (int64_t)(8 * grp + t) * tile_elems)[cell * 8 + q] = make_double2(s0, s1);
+                accS[2 * t] += s0; accS[2 * t + 1] += s1;
+                accT[2 * t] = fma(x0, s0, accT[2 * t]); accT[2 * t + 1] = fma(x1, s1, accT[2 * t + 1]);
+            }
+        }
+    }
+    // integers below 2^53: the order of these additions does not matter
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            atomicAdd(&shT[t * 16 + 2 * q + e], accT[2 * t + e]);
+            atomicAdd(&shS[t * 16 + 2 * q + e], accS[2 * t + e]);
+        }
+    __syncthreads();
+    if (threadIdx.x < 128 && chunk < chunks) {
+        const int t = threadIdx.x >> 4, slot = threadIdx.x & 15;
+        if (t < tiles_left) {
+            const int64_t tile = 8 * grp + t;
+            partial[((int64_t)tile * chunks + chunk) * SC_TILE + slot] = shT[threadIdx.x];
+            partial[((int64_t)(tiles16 + tile) * chunks + chunk) * SC_TILE + slot] = shS[threadIdx.x];
+        }
+    }
+}
+
 // Everything the permutation kernels need, from the loaded tiles and the active graph:
 //   value class + lattice decision per gene (one pass + one host sync), Z = X - centre, Lag = W Z (lattice genes: the
 //   unweighted neighbour sums of the raw counts), I, the per-gene finalisation constants, the narrow copy of the batch.
@@ -1193,18 +1269,41 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     hipLaunchKernelGGL(k_moran_centres, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
                        c->g_mean.as<double>(), c->g_lat.as<double>(), c->g_meanc.as<double>(), T * SC_TILE);
     // ---- operands ----
-    SC_TRY(expr_write_z(c, c->g_meanc.as<double>()));
-    SC_TRY(c->Lag.ensure((size_t)T * n * SC_TILE * sizeof(double), &c->mem));
-    SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>(),
-                      lat_any ? c->g_lat.as<double>() : nullptr));
-    SC_TRY(colsum<OP_MUL>(c, c->Z.as<double>(), c->Lag.as<double>(), c->g_Inum.as<double>(), 1.0));
     const size_t gb = (size_t)Gpad * sizeof(double);
     SC_TRY(c->g_slag.ensure(gb, &c->mem));
     SC_TRY(c->g_seff.ensure(gb, &c->mem));
     SC_TRY(c->g_corr.ensure(gb, &c->mem));
     SC_TRY(c->g_thr.ensure(gb, &c->mem));
     SC_TRY(c->g_I.ensure(gb, &c->mem));
-    if (lat_any) SC_TRY(colsum<OP_ID>(c, c->Lag.as<double>(), nullptr, c->g_slag.as<double>(), 1.0));
+    SC_TRY(c->Lag.ensure((size_t)T * n * SC_TILE * sizeof(double), &c->mem));
+    // an all-lattice uint8 batch (count data on a kNN graph): narrow copy first, then neighbour sums + both column sums
+    // from the uint8 rows in one pass (k_lag_u8); no Z tiles at all (the lattice operand IS the raw value)
+    const bool u8_prelude = n_perm > 0 && bits == 8 && lat_all && c->g_deg_max <= 257 && !getenv("SC_NO_U8_PRELUDE");
+    if (u8_prelude) {
+        SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
+        hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, 8)), dim3(256), 0,
+                           c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T);
+        const int chunks = (int)ceil_div64(n, LAG8_CELLS_PER_BLOCK);
+        SC_TRY(c->red_tmp.ensure(sizeof(double) * 2 * (size_t)T * chunks * SC_TILE, &c->mem));
+        const int32_t *order = (c->g_order_captured && c->g_n == n && c->g_order.p) ? c->g_order.as<int32_t>() : nullptr;
+        {
+            KernelTimerScope ts(c, SC_K_LAG);
+            hipLaunchKernelGGL(k_lag_u8, dim3((unsigned)align_up64(chunks, 8), (unsigned)ceil_div64(T, 8)), dim3(256), 0, c->stream,
+                               c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), c->X32.as<uint4>(), order, n, (int)T,
+                               (int64_t)n * SC_TILE, c->Lag.as<double>(), c->red_tmp.as<double>(), chunks);
+        }
+        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)T), dim3(SC_TILE), 0, c->stream, c->red_tmp.as<double>(),
+                           c->g_Inum.as<double>(), (double *)nullptr, chunks, 1.0);
+        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)T), dim3(SC_TILE), 0, c->stream,
+                           c->red_tmp.as<double>() + (size_t)T * chunks * SC_TILE, c->g_slag.as<double>(), (double *)nullptr, chunks, 1.0);
+        SC_HIP(hipGetLastError());
+    } else {
+        SC_TRY(expr_write_z(c, c->g_meanc.as<double>()));
+        SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>(),
+                          lat_any ? c->g_lat.as<double>() : nullptr));
+        SC_TRY(colsum<OP_MUL>(c, c->Z.as<double>(), c->Lag.as<double>(), c->g_Inum.as<double>(), 1.0));
+        if (lat_any) SC_TRY(colsum<OP_ID>(c, c->Lag.as<double>(), nullptr, c->g_slag.as<double>(), 1.0));
+    }
     SC_TRY(c->sims.ensure(sizeof(double) * (size_t)(T * SC_TILE) * (size_t)(n_perm > 0 ? n_perm : 1), &c->mem));
     hipLaunchKernelGGL(k_moran_scale, dim3((unsigned)ceil_div64(T * SC_TILE, 256)), dim3(256), 0, c->stream,
                        c->g_z2.as<double>(), c->g_Inum.as<double>(), c->g_slag.as<double>(), c->g_mean.as<double>(),
@@ -1220,7 +1319,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
         const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
         const size_t wide_rows = (size_t)splits64 * SC_TILE;
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
-        if (bits < 64) {
+        if (bits < 64 && !u8_prelude) {
             // the gathered operand: the raw values in the narrowest type that holds every gene of the batch exactly
             const int64_t T32 = (T + 1) / 2;
             SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= the uint16 / uint8 copies
@@ -1693,7 +1792,7 @@ extern "C" int sc_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, doub
 //   sc_moran_seeded_finish(ctx, state6, outputs)          prepares the operands and scores chunk after chunk.
 // Results and the final generator state are those of sc_moran_seeded.  A job that is begun and not finished is
 // dropped by sc_moran_seeded_abort, by any call that replaces the permutation table, and with the context.
-extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t n_cells, int64_t n_perm)
+extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t n_cells, int64_t n_perm, int64_t ahead_chunks)
 {
     SC_REQUIRE(c && state6, SC_ERR_INVALID, "sc_moran_seeded_begin: null pointer");
     SC_REQUIRE(n_perm >= 1 && n_perm <= (1 << 24), SC_ERR_INVALID, "sc_moran_seeded_begin: n_perm=%lld out of range", (long long)n_perm);
@@ -1703,7 +1802,11 @@ extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t 
     c->pg_ahead = PIPE_AHEAD;
     if (const char *v = getenv("SC_PIPE_AHEAD")) c->pg_ahead = atoi(v);
     PermPipe *pp = new PermPipe;
-    const int rc = pipe_begin(c, state6, n_cells, n_perm, permgen_can_swap_inverse(n_cells) ? 1 : 2, *pp, (int64_t)1 << 40);
+    // ahead_chunks: chunks of the generator enqueued before returning (a chunk is ~250 launches, ~3.5 ms of host time);
+    // 0 = all of them (a caller with tens of milliseconds of host-blocking work in front of _finish: an upload), else at
+    // least 2 (_finish enqueues the rest, two ahead of the scoring)
+    const int64_t ahead_n = ahead_chunks <= 0 ? (int64_t)1 << 40 : (ahead_chunks < 2 ? 2 : ahead_chunks);
+    const int rc = pipe_begin(c, state6, n_cells, n_perm, permgen_can_swap_inverse(n_cells) ? 1 : 2, *pp, ahead_n);
     c->pg_ahead = ahead;
     if (rc != SC_OK) { delete pp; return rc; }
     c->pipe = pp;

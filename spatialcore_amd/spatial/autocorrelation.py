@@ -255,6 +255,7 @@ def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_tab
     if n_permutations > 0 and reuse_table:
         out = ctx.moran(n_permutations, return_sims=False)
     elif n_permutations > 0 and begun is not None:
+        ctx.graph_moments()      # (needs the transposed graph: built here, beside the generator, not after the scoring)
         out = ctx.moran_seeded_finish(begun, return_sims=False)
     elif n_permutations > 0:
         # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1.  Table generation and
