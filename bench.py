@@ -312,13 +312,14 @@ def main() -> None:
 
     def device_part():
         nonlocal mem_peak
-        # the order morans_i itself uses: the permutation generator (it needs only n and the seed, and it is the longest
-        # chain of the step) starts first; graph, moments and scoring join it
-        begun = _lib.rng_state_words(np.random.default_rng(args.seed)) if P > 0 else None
-        if begun is not None:
-            ctx.moran_seeded_begin(begun, n, P, ahead_chunks=2)
+        # the neighbour search and the graph are enqueued without waiting (nothing is fetched), then the permutation
+        # generator -- it needs only n and the seed, and it is the longest chain of the step -- starts beside them with
+        # three chunks enqueued; the scoring joins it (morans_i starts the generator first as well: there an upload follows)
         ctx.knn(coords, k, fetch=False)
         ctx.graph_from_knn(1.0 / k)
+        begun = _lib.rng_state_words(np.random.default_rng(args.seed)) if P > 0 else None
+        if begun is not None:
+            ctx.moran_seeded_begin(begun, n, P, ahead_chunks=3)
         rows = []
         res = None
         for bi, (b0, b1) in enumerate(batches):

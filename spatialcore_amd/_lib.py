@@ -279,6 +279,7 @@ class Context:
         n = xy.shape[0]
         idx = np.empty((n, k), dtype=np.int32) if fetch else None
         rd = np.empty((n, k), dtype=np.float64) if (return_distance and fetch) else None
+        self._xy_in_flight = xy      # fetch=False returns without waiting: the upload may still be reading this array
         _check(self._lib.sc_knn_2d(self._h, _ptr(xy), n, int(k), int(include_self), _ptr(idx), _ptr(rd)))
         return (idx, rd) if return_distance else idx
 

@@ -158,11 +158,16 @@ int sc_ctx_destroy(sc_ctx *c)
     if (!c) return SC_OK;
     (void)hipSetDevice(c->device);
     sc_perm_pipe_abort(c);
+    sc_graph_moments_drain(c);
+    if (c->mom_host) (void)hipHostFree(c->mom_host);
+    if (c->mom_ready) (void)hipEventDestroy(c->mom_ready);
+    if (c->mom_done) (void)hipEventDestroy(c->mom_done);
+    if (c->stream_m) (void)hipStreamDestroy(c->stream_m);
     (void)hipStreamSynchronize(c->stream);
     DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,
                     &c->bin_keys2, &c->sid2, &c->cub_tmp, &c->knn_idx, &c->knn_rd, &c->knn_hd, &c->knn_hi, &c->rad_indptr,
                     &c->g_indptr, &c->g_indices, &c->g_data, &c->gt_indptr, &c->gt_indices,
-                    &c->gt_data, &c->gt_cursor, &c->X, &c->Z, &c->Lag, &c->X32, &c->inv, &c->e_tmp_indptr,
+                    &c->gt_data, &c->gt_cursor, &c->gt_tmp, &c->mom_dev, &c->X, &c->Z, &c->Lag, &c->X32, &c->inv, &c->e_tmp_indptr,
                     &c->e_tmp_indices, &c->e_tmp_data, &c->e_colmap, &c->g_mean, &c->g_var,
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,

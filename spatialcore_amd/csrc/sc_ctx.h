@@ -105,6 +105,14 @@ struct sc_ctx {
     int64_t g_deg_max = 0;      // longest row
     bool gt_valid = false;
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
+    // the full moments (transpose + reverse-edge search: 6 ms at 1M x 15) may be in flight on a side stream, begun by the
+    // scoring's set-up so that they leave its serial prelude (sc_graph.hip: graph_moments_begin / graph_moments)
+    hipStream_t stream_m = nullptr;
+    hipEvent_t mom_ready = nullptr, mom_done = nullptr;
+    bool mom_pending = false;
+    double *mom_host = nullptr;      // pinned: per-block partials of k_moments
+    int mom_blocks = 0;
+    DBuf gt_tmp, mom_dev;            // the transpose's own scan scratch (cub_tmp belongs to the neighbour search); k_moments' partials
     bool s0_valid = false, s0_only_valid = false;   // all three moments / s0 alone (k_weight_sum) are those of the active graph
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // graph moments (valid with s0_valid)
     // a processing order with spatial locality for kernels that read neighbours' rows (local Moran): the bin-sorted
@@ -249,6 +257,8 @@ static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b)
 // ---- implemented across translation units ----
 int sc_graph_ensure_transpose(sc_ctx *c);
 int sc_graph_ensure_s0(sc_ctx *c);
+int sc_graph_moments_begin(sc_ctx *c);   // start the full moments on the side stream (no host wait); collected by sc_graph_moments
+void sc_graph_moments_drain(sc_ctx *c);  // wait for a begun computation (before the graph's arrays are replaced)
 int sc_graph_capture_order(sc_ctx *c, int64_t n);  // called by the graph setters
 int sc_graph_ensure_order(sc_ctx *c);           // rank / relabelled columns / float weights, built on first use
 int sc_perm_generate_device(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm);

@@ -373,7 +373,9 @@ extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int incl
     if (rdist_out)
         SC_HIP(hipMemcpyAsync(rdist_out, c->knn_rd.p, sizeof(double) * (size_t)n * k, hipMemcpyDeviceToHost,
                               c->stream));
-    SC_HIP(hipStreamSynchronize(c->stream));
+    // nothing to hand back: the result stays on the device and every consumer is ordered behind it on the context's
+    // stream, so the host need not wait (the caller's coordinate array has been staged by the pageable-memory copy)
+    if (idx_out || rdist_out) SC_HIP(hipStreamSynchronize(c->stream));
     c->knn_n = n;
     c->knn_k = k;
     return SC_OK;
@@ -584,19 +586,22 @@ __global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ 
 }
 
 // The graph setters call this: if the points of the last neighbour search are the graph's cells (same count), a
-// spatially compact processing order is kept with the graph -- the cells along a Morton (Z) curve over the bin grid's
-// extent (r03; r02 kept the row-major bin order of the neighbour search, whose rows are ~3000 cells long at 1M cells:
-// a cell's neighbours in the bin rows above / below were 120 KB away and came from other XCDs' L2s) --, otherwise the
-// identity.  A wrong guess costs speed, never correctness: it is only the order in which kernels that gather
-// neighbours' rows (k_lag, local Moran, enrichment) walk the cells.
+// spatially compact processing order is kept with the graph (the bin-sorted order of the neighbour search, or a Morton
+// curve, see below), otherwise the identity.  A wrong guess costs speed, never correctness: it is only the order in which
+// kernels that gather neighbours' rows (k_lag, k_lag_u8, local Moran, enrichment) walk the cells.
 int sc_graph_capture_order(sc_ctx *c, int64_t n)
 {
     c->g_order_ready = false;
     SC_TRY(c->g_order.ensure(sizeof(int32_t) * (size_t)n, &c->mem));
-    static const char *order_env = getenv("SC_GRAPH_ORDER");   // development A/B: "rowmajor" = r02's bin order
-    if (order_env && order_env[0] == 'r' && c->pts_n == n && c->sid.p) {
+    // Default: the row-major bin order of the neighbour search (it is there already).  SC_GRAPH_ORDER=morton: a Morton (Z)
+    // curve over the bin grid's extent instead (one more radix sort, 1.5 ms at 1M cells) -- measured in r03 on k_lag, the
+    // local Moran count kernels and the enrichment: it cuts their L2 misses (k_lag: a third of the fetched bytes) but not
+    // their time (all of them are bound by the rows through the CUs' texture path, not by where they come from).
+    static const char *order_env = getenv("SC_GRAPH_ORDER");
+    const bool morton = order_env && order_env[0] == 'm';
+    if (!morton && c->pts_n == n && c->sid.p) {
         SC_HIP(hipMemcpyAsync(c->g_order.p, c->sid.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    } else if (c->pts_n == n && c->px.p && c->py.p && c->bin_keys.p && c->bin_keys2.p && c->sid2.p) {
+    } else if (morton && c->pts_n == n && c->px.p && c->py.p && c->bin_keys.p && c->bin_keys2.p && c->sid2.p) {
         const double ext = (double)(c->nbx > c->nby ? c->nbx : c->nby) * c->gh;
         hipLaunchKernelGGL(k_morton_keys, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream, c->px.as<double>(),
                            c->py.as<double>(), n, c->gx0, c->gy0, ext > 0.0 ? 1.0 / ext : 0.0, c->bin_keys.as<uint32_t>(),
@@ -655,6 +660,7 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
         if (data[e] != uniform_w) uniform_w = 0.0;
     if (!(uniform_w > 0.0) || uniform_w > 1e300) uniform_w = 0.0;
     SC_HIP(hipSetDevice(c->device));
+    sc_graph_moments_drain(c);   // (a moments computation on the side stream still reads the old arrays)
     c->g_n = 0;
     c->gt_valid = false;
     c->s0_valid = false;
@@ -711,6 +717,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
     SC_HIP(hipSetDevice(c->device));
     SC_REQUIRE(c->knn_n > 0, SC_ERR_STATE, "sc_graph_from_knn: no kNN result (call sc_knn_2d first)");
     int64_t n = c->knn_n, nnz = n * c->knn_k;
+    sc_graph_moments_drain(c);   // (a moments computation on the side stream still reads the old arrays)
     c->g_n = 0;
     c->gt_valid = false;
     c->s0_valid = false;
@@ -723,8 +730,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
                        c->g_indices.as<int32_t>(), c->g_data.as<double>());
     SC_HIP(hipGetLastError());
     SC_TRY(sc_graph_capture_order(c, n));
-    SC_HIP(hipStreamSynchronize(c->stream));
-    c->g_n = n;
+    c->g_n = n;     // (no host wait: consumers are ordered behind these launches on the context's stream)
     c->g_nnz = nnz;
     c->g_uniform_w = (weight > 0.0 && weight < 1e300) ? weight : 0.0;
     c->g_deg_max = c->knn_k;
@@ -799,9 +805,21 @@ __global__ __launch_bounds__(256) void k_sort_rows(const long long *__restrict__
     }
 }
 
+static int graph_build_transpose(sc_ctx *c, bool wait);
+
 int sc_graph_ensure_transpose(sc_ctx *c)
 {
-    if (c->gt_valid) return SC_OK;
+    if (c->gt_valid) {
+        // built on the side stream by a moments computation that may still be running: order this stream behind it
+        if (c->mom_pending && c->mom_done) SC_HIP(hipStreamWaitEvent(c->stream, c->mom_done, 0));
+        return SC_OK;
+    }
+    return graph_build_transpose(c, true);
+}
+
+// the transposed graph, built on c->stream (which the caller may have pointed at the side stream)
+static int graph_build_transpose(sc_ctx *c, bool wait)
+{
     SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
     int64_t n = c->g_n, nnz = c->g_nnz;
     SC_TRY(c->gt_indptr.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
@@ -816,8 +834,8 @@ int sc_graph_ensure_transpose(sc_ctx *c)
     size_t tmp_bytes = 0;
     SC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (long long *)cur, c->gt_indptr.as<long long>(),
                                             (int)(n + 1), c->stream));
-    SC_TRY(c->cub_tmp.ensure(tmp_bytes, &c->mem));
-    SC_HIP(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, (long long *)cur, c->gt_indptr.as<long long>(),
+    SC_TRY(c->gt_tmp.ensure(tmp_bytes, &c->mem));
+    SC_HIP(hipcub::DeviceScan::ExclusiveSum(c->gt_tmp.p, tmp_bytes, (long long *)cur, c->gt_indptr.as<long long>(),
                                             (int)(n + 1), c->stream));
     SC_HIP(hipMemcpyAsync(cur, c->gt_indptr.p, sizeof(long long) * (size_t)(n + 1), hipMemcpyDeviceToDevice,
                           c->stream));
@@ -827,7 +845,7 @@ int sc_graph_ensure_transpose(sc_ctx *c)
     hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, c->stream,
                        c->gt_indptr.as<long long>(), c->gt_indices.as<int32_t>(), c->gt_data.as<double>(), n);
     SC_HIP(hipGetLastError());
-    SC_HIP(hipStreamSynchronize(c->stream));
+    if (wait) SC_HIP(hipStreamSynchronize(c->stream));
     c->gt_valid = true;
     return SC_OK;
 }
@@ -884,6 +902,57 @@ __global__ __launch_bounds__(256) void k_moments(const long long *__restrict__ i
     if (threadIdx.x < 3) partial[(int64_t)blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
+// Start the full moments (s0, s1, s2) of the active graph on the SIDE stream, behind everything enqueued on the context
+// stream so far, and return without waiting: transpose, reverse-edge search and per-block partials into pinned host
+// memory.  The scoring's set-up calls this so that the 6 ms (1M cells x 15) leave its serial prelude; sc_graph_moments
+// collects.  Nothing else may replace the graph's arrays before sc_graph_moments_drain.
+int sc_graph_moments_begin(sc_ctx *c)
+{
+    if (c->s0_valid || c->mom_pending) return SC_OK;
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    const int64_t n = c->g_n;
+    const int blocks = (int)ceil_div64(n, MOM_ROWS_PER_BLOCK);
+    if (!c->stream_m) SC_HIP(hipStreamCreateWithFlags(&c->stream_m, hipStreamNonBlocking));
+    if (!c->mom_ready) SC_HIP(hipEventCreateWithFlags(&c->mom_ready, hipEventDisableTiming));
+    if (!c->mom_done) SC_HIP(hipEventCreateWithFlags(&c->mom_done, hipEventDisableTiming));
+    if (blocks > c->mom_blocks) {
+        if (c->mom_host) (void)hipHostFree(c->mom_host);
+        c->mom_host = nullptr;
+        SC_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->mom_host), sizeof(double) * 3 * (size_t)blocks, hipHostMallocDefault));
+        c->mom_blocks = blocks;
+    }
+    // every allocation the side stream's work needs happens here, on the host, before anything is enqueued
+    SC_TRY(c->gt_indptr.ensure(sizeof(long long) * (size_t)(n + 1), &c->mem));
+    SC_TRY(c->mom_dev.ensure(sizeof(double) * 3 * (size_t)blocks, &c->mem));
+    SC_HIP(hipEventRecord(c->mom_ready, c->stream));
+    SC_HIP(hipStreamWaitEvent(c->stream_m, c->mom_ready, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream_m;
+    int rc = c->gt_valid ? SC_OK : graph_build_transpose(c, false);
+    if (rc == SC_OK) {
+        hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), c->gt_indptr.as<long long>(),
+                           c->gt_data.as<double>(), n, c->mom_dev.as<double>());
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(c->mom_host, c->mom_dev.p, sizeof(double) * 3 * (size_t)blocks, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(c->mom_done, c->stream) != hipSuccess) {
+            sc_set_error("graph moments: launch on the side stream failed");
+            rc = SC_ERR_HIP;
+        }
+    }
+    c->stream = main_stream;
+    if (rc != SC_OK) { (void)hipStreamSynchronize(c->stream_m); return rc; }
+    c->mom_pending = true;
+    return SC_OK;
+}
+
+void sc_graph_moments_drain(sc_ctx *c)
+{
+    if (!c->mom_pending) return;
+    (void)hipEventSynchronize(c->mom_done);
+    c->mom_pending = false;
+}
+
 static int graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
 {
     SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
@@ -891,17 +960,11 @@ static int graph_moments(sc_ctx *c, double *s0, double *s1, double *s2)
         *s0 = c->s0; *s1 = c->s1; *s2 = c->s2;
         return SC_OK;
     }
-    SC_TRY(sc_graph_ensure_transpose(c));
-    int64_t n = c->g_n;
-    int blocks = (int)ceil_div64(n, MOM_ROWS_PER_BLOCK);
-    SC_TRY(c->red_tmp.ensure(sizeof(double) * 3 * (size_t)blocks, &c->mem));
-    hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
-                       c->g_indices.as<int32_t>(), c->g_data.as<double>(), c->gt_indptr.as<long long>(),
-                       c->gt_data.as<double>(), n, c->red_tmp.as<double>());
-    SC_HIP(hipGetLastError());
-    std::vector<double> h((size_t)blocks * 3);
-    SC_HIP(hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    SC_HIP(hipStreamSynchronize(c->stream));
+    SC_TRY(sc_graph_moments_begin(c));
+    SC_HIP(hipEventSynchronize(c->mom_done));
+    c->mom_pending = false;
+    const int blocks = (int)ceil_div64(c->g_n, MOM_ROWS_PER_BLOCK);
+    const double *h = c->mom_host;
     double a0 = 0, a1 = 0, a2 = 0;
     for (int b = 0; b < blocks; ++b) { a0 += h[3 * b]; a1 += h[3 * b + 1]; a2 += h[3 * b + 2]; }
     *s0 = a0; *s1 = a1 / 2.0; *s2 = a2;

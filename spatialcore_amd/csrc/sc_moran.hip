@@ -1233,6 +1233,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
     const int64_t Tpad = align_up64(T, 8), Gpad = Tpad * SC_TILE;
     SC_TRY(sc_graph_ensure_s0(c));
+    SC_TRY(sc_graph_moments_begin(c));   // s1, s2 (p_norm, z-scores): on the side stream, out of this serial prelude
     SC_TRY(expr_moments(c));
     // ---- value classes ----
     SC_TRY(c->g_flags.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem));
@@ -1280,6 +1281,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     // from the uint8 rows in one pass (k_lag_u8); no Z tiles at all (the lattice operand IS the raw value)
     const bool u8_prelude = n_perm > 0 && bits == 8 && lat_all && c->g_deg_max <= 257 && !getenv("SC_NO_U8_PRELUDE");
     if (u8_prelude) {
+        c->lm_valid = false;   // (Lag is about to be rewritten)
         SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
         hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, 8)), dim3(256), 0,
                            c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T);
