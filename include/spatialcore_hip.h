@@ -185,6 +185,12 @@ int sc_moran_seeded_begin(sc_ctx *ctx, const uint64_t *state6, int64_t n_cells, 
 int sc_moran_seeded_finish(sc_ctx *ctx, uint64_t *state6, double *I_out, double *sims_out, int64_t *count_ge_out,
                            double *sim_sum_out, double *sim_sumsq_out);
 int sc_moran_seeded_abort(sc_ctx *ctx);
+/* Optional, for a caller whose expression AND graph are resident before it begins the generator (a step that scores what
+ * is in HBM already): enqueue the first half of the preparation of sc_moran / sc_moran_seeded / _finish -- graph and gene
+ * moments, value classes -- now, without waiting for anything, so that the device works through it while the host
+ * enqueues the generator (sc_moran_seeded_begin right behind it).  The scoring call then finds it done.  Loading another
+ * expression or graph drops it.  No reference counterpart: pure scheduling, results unchanged. */
+int sc_moran_prepare_begin(sc_ctx *ctx);
 
 /* ---- A8: Lee's L ---------------------------------------------------------------------------
  * Replaces _compute_lees_l_core (AC:307-332) for a list of (x, y) pairs over the loaded genes.

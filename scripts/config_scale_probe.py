@@ -3,7 +3,8 @@
   enrich  neighborhood_enrichment, 1M cells, k = 30, ~20 cell types, 10 000 label permutations (BASELINE configs[4])
 usage: python scripts/config_scale_probe.py local|enrich [n_perm] [numpy|philox]"""
 import json, logging, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import make_adata
 from spatialcore_amd import _lib

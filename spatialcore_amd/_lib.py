@@ -58,6 +58,7 @@ SYMBOLS = {
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded_begin": [_P, _P, c_int64, c_int64, c_int64],
+    "sc_moran_prepare_begin": [_P],
     "sc_moran_seeded_finish": [_P, _P, _P, _P, _P, _P, _P],
     "sc_moran_seeded_abort": [_P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
@@ -411,6 +412,11 @@ class Context:
         enqueued before this returns (0 = all: for callers with an upload in front of the finish; else >= 2)."""
         _check(self._lib.sc_moran_seeded_begin(self._h, _ptr(words), int(n_cells), int(n_perm), int(ahead_chunks)))
         self._begun_perms = int(n_perm)
+
+    def moran_prepare_begin(self) -> None:
+        """Expression and graph resident: enqueue the first half of the Moran preparation now (no wait), in front of the
+        generator launches of moran_seeded_begin."""
+        _check(self._lib.sc_moran_prepare_begin(self._h))
 
     def moran_seeded_abort(self) -> None:
         _check(self._lib.sc_moran_seeded_abort(self._h))

@@ -160,6 +160,7 @@ int sc_ctx_destroy(sc_ctx *c)
     sc_perm_pipe_abort(c);
     sc_graph_moments_drain(c);
     if (c->mom_host) (void)hipHostFree(c->mom_host);
+    if (c->prep_host) (void)hipHostFree(c->prep_host);
     if (c->mom_ready) (void)hipEventDestroy(c->mom_ready);
     if (c->mom_done) (void)hipEventDestroy(c->mom_done);
     if (c->stream_m) (void)hipStreamDestroy(c->stream_m);
@@ -172,7 +173,7 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
                     &c->lee_b, &c->lee_out, &c->lee_pairs, &c->lee_U, &c->lee_Zc, &c->lee_Uc, &c->lee_part, &c->lee_obs, &c->lee_cnt,
-                    &c->lee_rowmap, &c->lee_lperm, &c->g_slag, &c->g_xsum, &c->g_flags, &c->g_xmax, &c->g_lat, &c->g_meanc, &c->g_seff, &c->g_corr, &c->g_thr, &c->sims_raw, &c->g_order, &c->g_rank, &c->g_indices_r, &c->g_w32, &c->g_erow_r, &c->lm_ys, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_flags, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
+                    &c->lee_rowmap, &c->lee_lperm, &c->g_slag, &c->g_xsum, &c->g_flags, &c->g_xmax, &c->g_lat, &c->g_meanc, &c->g_seff, &c->g_corr, &c->g_thr, &c->sims_raw, &c->g_order, &c->g_rank, &c->g_indices_r, &c->g_w32, &c->g_erow_r, &c->lm_ys, &c->lm_tab, &c->s0_tmp, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_flags, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
                     &c->pg_desc, &c->pg_tbits, &c->pg_events, &c->pg_hard,
                     &c->np_cnt, &c->np_comp, &c->np_leaves, &c->np_leafsum};
     for (DBuf *b : bufs) b->release(&c->mem);

@@ -163,7 +163,14 @@ struct sc_ctx {
     bool lm_direct = false;  // local Moran per-cell counts: the r01 one-kernel form instead of the two-phase sorted form (A/B)
     bool lm_valid = false;   // z / lag / counts of the last sc_local_moran are still resident
     int64_t lm_perms = 0;
-    DBuf lm_ys;              // local Moran: the permuted z rows of a batch of permutations, in the graph's processing order
+    DBuf lm_ys;              // local Moran: the permuted z rows (or uint8 code rows) of a batch of permutations, in the graph's processing order
+    DBuf lm_tab;             // local Moran, code rows: z and w z per (gene, value)
+    // first half of the Moran preparation, enqueued ahead of the generator by sc_moran_seeded_begin (sc_moran.hip)
+    bool prep_early = false;         // ... is in flight / done for the resident expression and graph
+    void *prep_host = nullptr;       // pinned: [weight-sum partials | xsum | flags | xmax]
+    size_t prep_host_cap = 0;
+    int prep_s0_blocks = 0;
+    DBuf s0_tmp;
     DBuf np_cnt, np_comp, np_leaves, np_leafsum;  // numpy-order column sums: block counts, compacted values, leaf table, leaf sums
 };
 
@@ -257,6 +264,9 @@ static inline int64_t align_up64(int64_t a, int64_t b) { return ceil_div64(a, b)
 // ---- implemented across translation units ----
 int sc_graph_ensure_transpose(sc_ctx *c);
 int sc_graph_ensure_s0(sc_ctx *c);
+int sc_graph_weight_sum_blocks(const sc_ctx *c);
+int sc_graph_weight_sum_launch(sc_ctx *c, double *pinned_out);                 // s0 without a host wait: launch + copy ...
+void sc_graph_weight_sum_collect(sc_ctx *c, const double *partial, int blocks);  // ... and the addition after the caller's synchronisation
 int sc_graph_moments_begin(sc_ctx *c);   // start the full moments on the side stream (no host wait); collected by sc_graph_moments
 void sc_graph_moments_drain(sc_ctx *c);  // wait for a begun computation (before the graph's arrays are replaced)
 int sc_graph_capture_order(sc_ctx *c, int64_t n);  // called by the graph setters

@@ -507,6 +507,7 @@ extern "C" int sc_radius_fill_2d(sc_ctx *c, int64_t nnz, int32_t *indices_out)
     c->gt_valid = false;
     c->s0_valid = false;
     c->s0_only_valid = false;
+    c->prep_early = false;
     return SC_OK;
 }
 
@@ -665,6 +666,7 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     c->gt_valid = false;
     c->s0_valid = false;
     c->s0_only_valid = false;
+    c->prep_early = false;
     SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
     SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
     SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
@@ -722,6 +724,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
     c->gt_valid = false;
     c->s0_valid = false;
     c->s0_only_valid = false;
+    c->prep_early = false;
     SC_TRY(c->g_indptr.ensure(sizeof(int64_t) * (size_t)(n + 1), &c->mem));
     SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)nnz, &c->mem));
     SC_TRY(c->g_data.ensure(sizeof(double) * (size_t)nnz, &c->mem));
@@ -1022,6 +1025,31 @@ int sc_graph_ensure_s0(sc_ctx *c)
     c->s0 = a0;
     c->s0_only_valid = true;
     return SC_OK;
+}
+
+// The same sum in two halves for a caller that must not wait (moran_prepare_early): launch + copy of the per-block
+// sums into the caller's pinned host array, and the host-side addition once the caller has synchronised.
+int sc_graph_weight_sum_blocks(const sc_ctx *c) { return (int)ceil_div64(c->g_n, MOM_ROWS_PER_BLOCK); }
+
+int sc_graph_weight_sum_launch(sc_ctx *c, double *pinned_out)
+{
+    SC_REQUIRE(c->g_n > 0, SC_ERR_STATE, "no graph set");
+    const int64_t n = c->g_n;
+    const int blocks = sc_graph_weight_sum_blocks(c);
+    SC_TRY(c->s0_tmp.ensure(sizeof(double) * (size_t)blocks, &c->mem));
+    hipLaunchKernelGGL(k_weight_sum, dim3(blocks), dim3(256), 0, c->stream, c->g_indptr.as<long long>(), c->g_data.as<double>(), n,
+                       c->s0_tmp.as<double>());
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(pinned_out, c->s0_tmp.p, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream));
+    return SC_OK;
+}
+
+void sc_graph_weight_sum_collect(sc_ctx *c, const double *partial, int blocks)
+{
+    double a0 = 0;
+    for (int b = 0; b < blocks; ++b) a0 += partial[b];   // (the order of sc_graph_ensure_s0)
+    c->s0 = a0;
+    c->s0_only_valid = true;
 }
 
 // y[i] = sum_e w[e] * x[col[e]]  for one contiguous vector

@@ -81,6 +81,7 @@ static int expr_alloc(sc_ctx *c, int64_t n, int64_t n_genes)
     c->narrow_bits = 64;
     c->lat_any = false;
     c->lm_valid = false;
+    c->prep_early = false;
     return SC_OK;
 }
 
@@ -922,12 +923,18 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
 // block b); its first stage also issues the lag load of the NEXT super-block, its last stage parks it in the other LDS
 // buffer and ends with the barrier.  The pipelined region has NO branch: hipcc's wait-count pass answers a divergent
 // path with s_waitcnt vmcnt(0), which would drain the gathers in flight (measured in the ISA of two earlier forms: a
-// loader-wavefront `if`, and a skip for wavefronts beyond the chunk's permutations).  Hence: narrower sources, whose 16
-// cells have fewer than 1024 pieces, load some pieces twice (same bytes to the same LDS address), and wavefronts beyond
-// the chunk's permutations score their clamped permutation again and drop the result -- the host sends chunks that would
-// idle more than a quarter of a task's wavefronts (the pipeline's short first / last chunk) to k_moran_score instead.
+// loader-wavefront `if`, and a skip for wavefronts beyond the chunk's permutations INSIDE the loop).  Hence: narrower
+// sources, whose 16 cells have fewer than 1024 pieces, load some pieces twice (same bytes to the same LDS address); and a
+// wavefront beyond the chunk's permutations (a chunk shorter than 128) takes a loop of its own, chosen by a
+// wavefront-uniform branch OUTSIDE the pipelined loop: it only carries its pieces of the lag rows into LDS and meets the
+// same barriers.  What bounds the kernel is the bytes a compute unit pulls in, so a short chunk costs about its share of a
+// full one while enough wavefronts are left to keep the memory path busy; the host sends chunks with fewer than
+// SCORE_WG_MIN_PERMS permutations in their last task to k_moran_score instead.
 // ------------------------------------------------------------------------------------------------
 #define SCORE_SB 16   // cells per lag super-block
+#ifndef SCORE_WG_MIN_PERMS
+#define SCORE_WG_MIN_PERMS 24   // permutations in a chunk's last (partial) task from which the workgroup form is used
+#endif
 
 template <int BITS, int CB, bool BIG>
 __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
@@ -955,8 +962,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         const int pch = (int)(task % pchunks);
         const int64_t rest = task / pchunks;
         const int split = (int)(rest % n_splits), grp = (int)(rest / n_splits);
-        const int pbase = (pch * SCORE_WAVES + wave) * 8;
-        const bool live = pbase < n_perm;          // wavefront-uniform
+        const int pbase = (pch * SCORE_WAVES + (BITS != 64 ? __builtin_amdgcn_readfirstlane(wave) : wave)) * 8;
+        const bool live = pbase < n_perm;          // wavefront-uniform (and known to the compiler as such)
         const int p = pbase + r;
         const int pc = p < n_perm ? p : n_perm - 1;
         const int64_t c0 = (int64_t)split * cells_per_split;
@@ -1044,7 +1051,20 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             }
         };
 
-        if (nsb > 0) {
+        if (BITS != 64 && nsb > 0 && !live) {
+            // (the fp64-row form has no registers to spare for a second loop: its idle wavefronts score their clamped
+            // permutation again, and the host keeps short chunks away from it)
+            // a wavefront beyond the chunk's permutations only carries its pieces of the lag rows into LDS: the same
+            // barriers as the scoring loop below, no gathers (the branch is wavefront-uniform and OUTSIDE that loop)
+            load_lag(0);
+            lds_lag[0][pid] = lg;
+            __syncthreads();
+            for (int64_t sb = 0; sb < nsb; ++sb) {
+                load_lag(sb + 1);
+                lds_lag[(sb + 1) & 1][pid] = lg;
+                __syncthreads();
+            }
+        } else if (nsb > 0) {
             int4 id0[NI], id1[NI], id2[NI], id3[NI];   // indices of blocks b + 1 .. b + SPS at the top of a trip (id0 .. id1 when SPS == 2)
             load_lag(0);
             load_idx(id3, 0);
@@ -1228,11 +1248,29 @@ __global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ in
 //   unweighted neighbour sums of the raw counts), I, the per-gene finalisation constants, the narrow copy of the batch.
 // allow_lattice = false: ordinary arithmetic for every gene (tables that are not permutations: the identity
 // sum_j x[idx[j]] = sum_j x[j] behind the lattice form does not hold for them).
-static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
+// First half of moran_prepare: everything that needs neither a decision of the host nor the permutation count -- the
+// weight sum, the graph moments (side stream), the gene moments and value classes -- is enqueued, with its small results
+// on their way into pinned host memory, and NOTHING is waited for.  sc_moran_seeded_begin calls it in front of the
+// generator's launches when expression and graph are resident already (the generator takes ~10 ms of host time to
+// enqueue; the device works through this half meanwhile).  Any change of the expression or the graph drops it.
+static int moran_prepare_early(sc_ctx *c)
 {
-    const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
-    const int64_t Tpad = align_up64(T, 8), Gpad = Tpad * SC_TILE;
-    SC_TRY(sc_graph_ensure_s0(c));
+    const int64_t n = c->e_n, T = c->e_tiles;
+    const int64_t Gpad = align_up64(T, 8) * SC_TILE;
+    SC_REQUIRE(n > 0 && c->g_n == n, SC_ERR_STATE, "internal: early preparation without expression and graph");
+    const bool need_s0 = !(c->s0_valid || c->s0_only_valid);
+    const int blocks = need_s0 ? sc_graph_weight_sum_blocks(c) : 0;
+    const size_t bytes = sizeof(double) * ((size_t)blocks + (size_t)(T * SC_TILE)) + sizeof(uint32_t) * 2 * (size_t)Gpad;
+    if (bytes > c->prep_host_cap) {
+        if (c->prep_host) (void)hipHostFree(c->prep_host);
+        c->prep_host = nullptr; c->prep_host_cap = 0;
+        SC_HIP(hipHostMalloc(&c->prep_host, bytes, hipHostMallocDefault));
+        c->prep_host_cap = bytes;
+    }
+    double *h_s0 = reinterpret_cast<double *>(c->prep_host), *h_xsum = h_s0 + blocks;
+    uint32_t *h_flags = reinterpret_cast<uint32_t *>(h_xsum + T * SC_TILE), *h_xmax = h_flags + Gpad;
+    c->prep_s0_blocks = blocks;
+    if (need_s0) SC_TRY(sc_graph_weight_sum_launch(c, h_s0));
     SC_TRY(sc_graph_moments_begin(c));   // s1, s2 (p_norm, z-scores): on the side stream, out of this serial prelude
     SC_TRY(expr_moments(c));
     // ---- value classes ----
@@ -1243,12 +1281,24 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     hipLaunchKernelGGL(k_gene_stats, dim3((unsigned)ceil_div64(n, RED_ROWS_PER_BLOCK), (unsigned)T), dim3(256), 0, c->stream,
                        c->X.as<double>(), n, c->g_flags.as<uint32_t>(), c->g_xmax.as<uint32_t>());
     SC_HIP(hipGetLastError());
-    std::vector<uint32_t> flags((size_t)Gpad), xmax((size_t)Gpad);
-    std::vector<double> xsum((size_t)(T * SC_TILE)), lat((size_t)Gpad, 0.0);
-    SC_HIP(hipMemcpyAsync(flags.data(), c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
-    SC_HIP(hipMemcpyAsync(xmax.data(), c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
-    SC_HIP(hipMemcpyAsync(xsum.data(), c->g_xsum.p, sizeof(double) * xsum.size(), hipMemcpyDeviceToHost, c->stream));
-    SC_HIP(hipStreamSynchronize(c->stream));
+    SC_HIP(hipMemcpyAsync(h_flags, c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(h_xmax, c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(h_xsum, c->g_xsum.p, sizeof(double) * (size_t)(T * SC_TILE), hipMemcpyDeviceToHost, c->stream));
+    c->prep_early = true;
+    return SC_OK;
+}
+
+static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
+{
+    const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
+    const int64_t Tpad = align_up64(T, 8), Gpad = Tpad * SC_TILE;
+    if (!c->prep_early) SC_TRY(moran_prepare_early(c));
+    c->prep_early = false;
+    SC_HIP(hipStreamSynchronize(c->stream));   // the ONE synchronisation of the preparation
+    const double *h_s0 = reinterpret_cast<const double *>(c->prep_host), *xsum = h_s0 + c->prep_s0_blocks;
+    const uint32_t *flags = reinterpret_cast<const uint32_t *>(xsum + T * SC_TILE), *xmax = flags + Gpad;
+    if (c->prep_s0_blocks > 0) sc_graph_weight_sum_collect(c, h_s0, c->prep_s0_blocks);
+    std::vector<double> lat((size_t)Gpad, 0.0);
     int bits = c->source_bits_min;
     bool lat_any = false, lat_all = true;
     const bool lattice_graph = allow_lattice && c->g_uniform_w > 0.0;
@@ -1394,10 +1444,12 @@ template <int BITS, int CB, bool BIG>
 static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int cnt, int64_t cps, int splits, int groups)
 {
     static const bool private_lag = getenv("SC_SCORE_PRIVATE_LAG") != nullptr;   // development: the r02 form, for A/B runs
-    // the workgroup form scores 128 permutations per task; a chunk that would leave more than a quarter of the last
-    // task's wavefronts idle (the pipeline's short first and last chunks) takes the per-wavefront form -- same results
-    const int idle = (8 * SCORE_WAVES - cnt % (8 * SCORE_WAVES)) % (8 * SCORE_WAVES);
-    if (!private_lag && idle <= 2 * SCORE_WAVES) {
+    // the workgroup form scores 128 permutations per task; wavefronts beyond a short chunk's permutations only help with
+    // the lag rows.  Below SCORE_WG_MIN_PERMS live permutations a compute unit has too few gathers in flight: such chunks
+    // take the per-wavefront form -- same results (SC_SCORE_WG_MIN: development, to sweep the threshold)
+    static const int wg_min = getenv("SC_SCORE_WG_MIN") ? atoi(getenv("SC_SCORE_WG_MIN")) : SCORE_WG_MIN_PERMS;
+    const int last_task = cnt % (8 * SCORE_WAVES);
+    if (!private_lag && (last_task == 0 || last_task >= (BITS == 64 ? 6 * SCORE_WAVES : wg_min))) {
         const int64_t tasks = (int64_t)groups * splits * ((cnt + 8 * SCORE_WAVES - 1) / (8 * SCORE_WAVES));
         if (wgs > tasks) wgs = (int)tasks;
         hipLaunchKernelGGL((k_moran_score_wg<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
@@ -1549,7 +1601,7 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
 #define PIPE_FIRST 32        // permutations of the first pipeline chunk
 #endif
 #ifndef PIPE_LAST
-#define PIPE_LAST 48         // ... of the last one (0: none in particular)
+#define PIPE_LAST 32         // ... of the last one (0: none in particular)
 #endif
 #ifndef PIPE_SWAP_STREAMS
 #define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
@@ -1634,9 +1686,10 @@ static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_pe
     if (n_perm > 3 * PERM_CHUNK) {
         const int64_t first = pipe_first_perms(), last = pipe_last_perms();
         const int64_t rest = (n_perm - last - first) % PERM_CHUNK;
-        int64_t p = first + (rest < PERM_CHUNK / 2 ? rest : 0);  // a small remainder joins the first chunk
+        static const bool join = getenv("SC_PIPE_JOIN") != nullptr;   // development: a small remainder joins the first chunk (r02 / early r03)
+        int64_t p = first + (join && rest < PERM_CHUNK / 2 ? rest : 0);
         pp.bounds.push_back(p);
-        if (rest >= PERM_CHUNK / 2) { p += rest; pp.bounds.push_back(p); }
+        if (p == first && rest > 0) { p += rest; pp.bounds.push_back(p); }   // the remainder: a chunk of its own, second
         for (; p < n_perm - last; ) { p += PERM_CHUNK; pp.bounds.push_back(p); }
         if (last > 0) pp.bounds.push_back(n_perm);
     } else {
@@ -1813,6 +1866,20 @@ extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t 
     if (rc != SC_OK) { delete pp; return rc; }
     c->pipe = pp;
     return SC_OK;
+}
+
+// For a caller whose expression and graph are resident BEFORE it begins the generator: enqueue the first half of the
+// preparation (graph and gene moments, value classes; see moran_prepare_early) now, in front of the generator's
+// launches -- these take the host ~10 ms to enqueue, the device works through this half meanwhile.  Optional: without
+// it sc_moran / sc_moran_seeded / _finish do the same work when they start.  Nothing is waited for.
+extern "C" int sc_moran_prepare_begin(sc_ctx *c)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_moran_prepare_begin: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_moran_prepare_begin: graph missing or size mismatch");
+    if (c->prep_early) return SC_OK;
+    return moran_prepare_early(c);
 }
 
 extern "C" int sc_moran_seeded_abort(sc_ctx *c)
@@ -2350,6 +2417,133 @@ __global__ __launch_bounds__(256) void k_lm_count_sorted(const long long *__rest
     else { const int4 c0 = *dst; *dst = make_int4(c0.x + cx, c0.y + cy, c0.z + cz, c0.w + cw); }
 }
 
+// ---- the two phases over CODE rows (r03): count data, every value an integer in [0, LM_CODES) ----
+// A gene with few distinct values has few distinct z: z = table[gene][value].  The permuted matrix of a batch is then
+// moved around as the uint8 rows of the scoring kernel's narrow copy (128 genes per 128-byte row instead of 16 per
+// 64-byte float tile row: an eighth of the gathered, written and re-read bytes), and the float32 z of a neighbour is
+// looked up in LDS when it is used.  table[gene][v] is k_lm_standardize's own expression at x = v, so every product
+// and every sum is the float path's, bit for bit.  With all weights equal (a row-normalised kNN graph) a second table
+// holds w * z, the product the float path rounds before it adds.
+#define LM_CODES 32          // values 0 .. 31
+#define LM_TAB_STRIDE 36     // floats per table row: (q, value) pairs of one load land in different LDS banks for small values
+#define LM_U8_QUAD 4         // permutations in flight per thread
+#define LM_U8_BATCH_MAX 32   // permutations per launch (the counts are read and written once per launch)
+
+// table rows in the order the kernel's threads use them: row = 8 b + q holds the gene of byte b of lane q's 16 bytes
+// of a narrow row (k_pack_narrow<8>: tile 8 grp + b / 2, slot 2 q + b % 2);  tab[0] = z, tab[1] = w z
+__global__ __launch_bounds__(256) void k_lm_ztab(const float *__restrict__ mean32, const float *__restrict__ sd32,
+                                                 int64_t tiles16, float w, float *__restrict__ tab, int groups)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * 128 * LM_TAB_STRIDE) return;
+    const int v = t % LM_TAB_STRIDE, row = (t / LM_TAB_STRIDE) % 128, grp = t / (LM_TAB_STRIDE * 128);
+    const int b = row >> 3, q = row & 7;
+    const int64_t tile = 8 * (int64_t)grp + (b >> 1);
+    float z = 0.f;
+    if (tile < tiles16 && v < LM_CODES) {
+        const int64_t g = tile * SC_TILE + 2 * q + (b & 1);
+        z = (float)__ddiv_rn((double)__fsub_rn((float)v, mean32[g]), (double)sd32[g]);
+    }
+    tab[t] = z;
+    tab[(size_t)groups * 128 * LM_TAB_STRIDE + t] = __fmul_rn(w, z);
+}
+
+// Ys8[p][grp][r] = X8[grp][perm_p[order[r]]]   thread = (r, q), grid.y = group, grid.z = permutation of the batch
+__global__ __launch_bounds__(256) void k_lm_gather_u8(const uint4 *__restrict__ X8, const int32_t *__restrict__ order,
+                                                      const int32_t *__restrict__ perm, int64_t pstride, int64_t n,
+                                                      int groups, uint4 *__restrict__ Ys8)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 3;
+    const int q = (int)(t & 7);
+    if (r >= n) return;
+    const int32_t src = perm[(int64_t)blockIdx.z * pstride + order[r]];
+    Ys8[(((int64_t)blockIdx.z * groups + blockIdx.y) * n + r) * 8 + q] = X8[((int64_t)blockIdx.y * n + src) * 8 + q];
+}
+
+// count[tile][cell][16] += #{p in batch : |y[r] * sum_e w_e y[rank(col_e)]| >= |I[cell]|}, y = table[code], cell = order[r]
+// thread = (r, q): the 16 genes of lane q's 16 bytes, LM_U8_QUAD permutations at a time; edges in the row's order.
+template <bool UNI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 3, 4))) void k_lm_count_u8(const long long *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices_r, const float *__restrict__ w32,
+                                                     const int32_t *__restrict__ order, const uint4 *__restrict__ Ys8,
+                                                     const float *__restrict__ I32, const float *__restrict__ tab,
+                                                     int n_batch, int64_t tiles, int groups, int32_t *__restrict__ count,
+                                                     int64_t n, int first)
+{
+    __shared__ float tz[128 * LM_TAB_STRIDE];
+    __shared__ float tw[UNI ? 128 * LM_TAB_STRIDE : 1];
+    const int grp = blockIdx.y;
+    for (int k = threadIdx.x; k < 128 * LM_TAB_STRIDE; k += 256) {
+        tz[k] = tab[(size_t)grp * 128 * LM_TAB_STRIDE + k];
+        if (UNI) tw[k] = tab[((size_t)groups + grp) * 128 * LM_TAB_STRIDE + k];
+    }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 3;
+    const int q = (int)(t & 7);
+    if (r >= n) return;
+    const int64_t i = order[r];
+    float a[16];
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};   // 16 counts of <= LM_U8_BATCH_MAX, 8 bits each
+    static_assert(LM_U8_BATCH_MAX < 256, "packed per-launch counts");
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int64_t tile = 8 * (int64_t)grp + (b >> 1);
+        a[b] = tile < tiles ? fabsf(I32[tile * n * SC_TILE + i * SC_TILE + 2 * q + (b & 1)]) : 0.f;
+    }
+    const long long e0 = indptr[i], e1 = indptr[i + 1];
+    const int64_t pstep = (int64_t)groups * n * 8;   // uint4 stride between the permutations of the batch
+    const uint4 *Y0 = Ys8 + (int64_t)grp * n * 8 + q;
+    const float *zq = tz + q * LM_TAB_STRIDE;         // + b * 8 * LM_TAB_STRIDE + value
+    const float *wq = (UNI ? tw : tz) + q * LM_TAB_STRIDE;
+    for (int p0 = 0; p0 < n_batch; p0 += LM_U8_QUAD) {
+        float s[LM_U8_QUAD][16];
+#pragma unroll
+        for (int p = 0; p < LM_U8_QUAD; ++p)
+#pragma unroll
+            for (int b = 0; b < 16; ++b) s[p][b] = 0.f;
+        for (long long e = e0; e < e1; ++e) {
+            const float ww = w32[e];
+            const uint4 *Ye = Y0 + (int64_t)indices_r[e] * 8 + (int64_t)p0 * pstep;
+            uint4 row[LM_U8_QUAD];
+#pragma unroll
+            for (int p = 0; p < LM_U8_QUAD; ++p) row[p] = p0 + p < n_batch ? Ye[p * pstep] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int p = 0; p < LM_U8_QUAD; ++p) {
+                const uint32_t wd[4] = {row[p].x, row[p].y, row[p].z, row[p].w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t v = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    const float term = UNI ? wq[b * 8 * LM_TAB_STRIDE + v] : __fmul_rn(ww, zq[b * 8 * LM_TAB_STRIDE + v]);
+                    s[p][b] = __fadd_rn(s[p][b], term);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < LM_U8_QUAD; ++p) {
+            if (p0 + p < n_batch) {
+                const uint4 own = Y0[r * 8 + (int64_t)(p0 + p) * pstep];
+                const uint32_t wd[4] = {own.x, own.y, own.z, own.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t v = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    cnt[b >> 2] += (fabsf(__fmul_rn(zq[b * 8 * LM_TAB_STRIDE + v], s[p][b])) >= a[b] ? 1u : 0u) << (8 * (b & 3));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int64_t tile = 8 * (int64_t)grp + tt;
+        if (tile >= tiles) continue;
+        int2 *dst = reinterpret_cast<int2 *>(count + tile * n * SC_TILE + i * SC_TILE + 2 * q);
+        const int ca = (int)((cnt[tt >> 1] >> (16 * (tt & 1))) & 0xffu), cb = (int)((cnt[tt >> 1] >> (16 * (tt & 1) + 8)) & 0xffu);
+        if (first) *dst = make_int2(ca, cb);
+        else { const int2 c0 = *dst; *dst = make_int2(c0.x + ca, c0.y + cb); }
+    }
+}
+
 // tile layout [tile][cell][16] -> row-major [cell][n_genes]
 template <typename T>
 __global__ __launch_bounds__(256) void k_untile(const T *__restrict__ tiles, T *__restrict__ out, int64_t n,
@@ -2359,6 +2553,30 @@ __global__ __launch_bounds__(256) void k_untile(const T *__restrict__ tiles, T *
     if (t >= n * n_genes) return;
     int64_t i = t / n_genes, g = t - i * n_genes;
     out[t] = tiles[(g >> 4) * n * SC_TILE + i * SC_TILE + (g & 15)];
+}
+
+// Is every loaded value an integer in [0, LM_CODES)?  (one pass over the tiles + one synchronisation; SC_LM_FLOAT_ROWS
+// set: development switch, the float-row form for A/B runs and tests)
+static bool lm_codes_ok(sc_ctx *c)
+{
+    if (getenv("SC_LM_FLOAT_ROWS") || c->e_n >= ((int64_t)1 << 24)) return false;
+    const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
+    const int64_t Gpad = align_up64(T, 8) * SC_TILE;
+    if (c->g_flags.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem) != SC_OK || c->g_xmax.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem) != SC_OK)
+        return false;
+    if (hipMemsetAsync(c->g_flags.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->g_xmax.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(k_gene_stats, dim3((unsigned)ceil_div64(n, RED_ROWS_PER_BLOCK), (unsigned)T), dim3(256), 0, c->stream,
+                       c->X.as<double>(), n, c->g_flags.as<uint32_t>(), c->g_xmax.as<uint32_t>());
+    std::vector<uint32_t> flags((size_t)Gpad), xmax((size_t)Gpad);
+    if (hipMemcpyAsync(flags.data(), c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(xmax.data(), c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return false;
+    for (int64_t g = 0; g < G; ++g)
+        if ((flags[(size_t)g] & 1u) || xmax[(size_t)g] >= LM_CODES) return false;
+    return true;
 }
 
 extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
@@ -2441,6 +2659,34 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
         hipLaunchKernelGGL(k_lm_perm_count, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                            c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, I32,
                            c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, cnt, n);
+    } else if (n_perm > 0 && lm_codes_ok(c)) {
+        // count data: the permuted matrix travels as uint8 code rows, z is looked up where it is used (k_lm_count_u8)
+        SC_TRY(sc_graph_ensure_order(c));
+        const int groups = (int)ceil_div64(T, 8);
+        const size_t row_bytes = (size_t)groups * (size_t)n * 128;
+        SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
+        SC_TRY(c->lm_tab.ensure(sizeof(float) * 2 * (size_t)groups * 128 * LM_TAB_STRIDE, &c->mem));
+        int64_t batch = (int64_t)(((size_t)4 << 30) / row_bytes) / LM_U8_QUAD * LM_U8_QUAD;
+        batch = batch < LM_U8_QUAD ? LM_U8_QUAD : batch > LM_U8_BATCH_MAX ? LM_U8_BATCH_MAX : batch;
+        if (batch > n_perm) batch = align_up64(n_perm, LM_U8_QUAD);
+        SC_TRY(c->lm_ys.ensure(row_bytes * (size_t)batch, &c->mem));
+        hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)groups), dim3(256), 0, c->stream,
+                           c->X.as<double>(), c->X32.as<uint4>(), n, T);
+        const bool uni = c->g_uniform_w > 0.0;
+        hipLaunchKernelGGL(k_lm_ztab, dim3((unsigned)ceil_div64((int64_t)groups * 128 * LM_TAB_STRIDE, 256)), dim3(256), 0, c->stream,
+                           mean32, sd32, T, uni ? (float)c->g_uniform_w : 0.f, c->lm_tab.as<float>(), groups);
+        KernelTimerScope ts(c, SC_K_LEE_PERM);
+        const dim3 g8((unsigned)ceil_div64(n * 8, 256), (unsigned)groups);
+        auto count_u8 = uni ? k_lm_count_u8<true> : k_lm_count_u8<false>;
+        for (int64_t p0 = 0; p0 < n_perm; p0 += batch) {
+            const int nb = (int)(n_perm - p0 < batch ? n_perm - p0 : batch);
+            hipLaunchKernelGGL(k_lm_gather_u8, dim3(g8.x, g8.y, (unsigned)nb), dim3(256), 0, c->stream, c->X32.as<uint4>(),
+                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (perm_row0 + p0) * c->p_stride, c->p_stride,
+                               n, groups, c->lm_ys.as<uint4>());
+            hipLaunchKernelGGL(count_u8, g8, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                               c->g_indices_r.as<int32_t>(), c->g_w32.as<float>(), c->g_order.as<int32_t>(),
+                               c->lm_ys.as<uint4>(), I32, c->lm_tab.as<float>(), nb, T, groups, cnt, n, p0 == 0 ? 1 : 0);
+        }
     } else if (n_perm > 0) {
         SC_TRY(sc_graph_ensure_order(c));
         SC_TRY(c->lm_ys.ensure(sizeof(float) * (size_t)LM_PERM_BATCH * tile_f, &c->mem));

@@ -600,6 +600,52 @@ def test_numpy_order_column_sums_large(ctx, dtype):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("uniform", [True, False])
+def test_local_moran_code_rows_equal_float_rows(ctx, monkeypatch, uniform):
+    """Count data (every value an integer below 32) travels through the per-cell permutation counts as uint8 code rows
+    with z looked up per (gene, value) (k_lm_gather_u8 / k_lm_count_u8; with equal weights also w * z from a table).  The
+    counts must be those of the float-row form (SC_LM_FLOAT_ROWS), cell for cell: 150 genes = two 128-gene groups with a
+    ragged second one, 37 permutations = a ragged last quad, on a row-normalised kNN graph and on a graph with unequal
+    weights.  A value of 32 or a non-integer sends the call to the float rows by itself (same counts again)."""
+    from scipy import sparse
+    from spatialcore_amd._lib import rng_state_words
+
+    n, G, P, k = 5000, 150, 37, 6
+    rng = np.random.default_rng(5)
+    coords = rng.uniform(0, 700.0, (n, 2))
+    X = rng.poisson(rng.uniform(0.05, 4.0, G), (n, G)).astype(np.float32)
+    X[X > 31] = 31
+    X[:, 7] = 0                      # zero variance
+    idx = ctx.knn(coords, k)
+    if uniform:
+        ctx.graph_from_knn(1.0 / k)
+    else:
+        w = rng.uniform(0.1, 1.0, (n, k))
+        W = sparse.csr_matrix((w.ravel(), idx.ravel().astype(np.int32), np.arange(0, n * k + 1, k)), shape=(n, n))
+        W.sort_indices()
+        ctx.set_graph_csr(W.indptr, W.indices, W.data, n)
+
+    def run(Xm):
+        ctx.set_expression(Xm, np.arange(G))
+        ctx.generate_permutations(rng_state_words(np.random.default_rng(9)), n, P)
+        return ctx.local_moran(n, P)
+
+    got = run(X)
+    monkeypatch.setenv("SC_LM_FLOAT_ROWS", "1")
+    want = run(X)
+    monkeypatch.delenv("SC_LM_FLOAT_ROWS")
+    for f in ("z", "lag", "I", "count"):
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    assert got["count"].max() <= P and got["count"].sum() > 0
+    for bad in (32.0, 0.5):
+        Xb = X.copy(); Xb[11, 3] = bad
+        a = run(Xb)
+        monkeypatch.setenv("SC_LM_FLOAT_ROWS", "1")
+        b = run(Xb)
+        monkeypatch.delenv("SC_LM_FLOAT_ROWS")
+        np.testing.assert_array_equal(a["count"], b["count"])
+
+
 def test_lee_vs_reference_golden(ctx, oracle):
     from spatialcore_amd._lib import rng_state_words
 
