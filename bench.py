@@ -319,8 +319,6 @@ def main() -> None:
         ctx.graph_from_knn(1.0 / k)
         begun = _lib.rng_state_words(np.random.default_rng(args.seed)) if P > 0 else None
         if begun is not None:
-            if len(batches) == 1 and not os.environ.get("SC_NO_EARLY_PREP"):
-                ctx.moran_prepare_begin()   # expression resident: moments and value classes go in front of the generator's launches
             ctx.moran_seeded_begin(begun, n, P, ahead_chunks=3)
         rows = []
         res = None

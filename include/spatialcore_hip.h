@@ -185,12 +185,6 @@ int sc_moran_seeded_begin(sc_ctx *ctx, const uint64_t *state6, int64_t n_cells, 
 int sc_moran_seeded_finish(sc_ctx *ctx, uint64_t *state6, double *I_out, double *sims_out, int64_t *count_ge_out,
                            double *sim_sum_out, double *sim_sumsq_out);
 int sc_moran_seeded_abort(sc_ctx *ctx);
-/* Optional, for a caller whose expression AND graph are resident before it begins the generator (a step that scores what
- * is in HBM already): enqueue the first half of the preparation of sc_moran / sc_moran_seeded / _finish -- graph and gene
- * moments, value classes -- now, without waiting for anything, so that the device works through it while the host
- * enqueues the generator (sc_moran_seeded_begin right behind it).  The scoring call then finds it done.  Loading another
- * expression or graph drops it.  No reference counterpart: pure scheduling, results unchanged. */
-int sc_moran_prepare_begin(sc_ctx *ctx);
 
 /* ---- A8: Lee's L ---------------------------------------------------------------------------
  * Replaces _compute_lees_l_core (AC:307-332) for a list of (x, y) pairs over the loaded genes.
@@ -235,6 +229,12 @@ int sc_lee_shared(sc_ctx *ctx, uint64_t *state6, const int32_t *genes_x, int32_t
  * float32 sd is 0 (AC:825-830; the caller blanks those columns, AC:902-906). */
 int sc_local_moran(sc_ctx *ctx, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
                    float *I_out, int32_t *count_out, uint8_t *zero_var_out);
+/* The same batch with its permutations drawn here: n_perm numpy-exact permutations from state6 (exactly the rows
+ * sc_perm_generate would leave; state6 advanced the same way: AC:839,879, one stream across the batches), generated
+ * chunk by chunk while the per-cell counts of the finished chunks are taken.  Count data (every value an integer below
+ * 32) travels through the counts as uint8 code rows with z looked up per (gene, value); outputs identical either way. */
+int sc_local_moran_seeded(sc_ctx *ctx, uint64_t *state6, int64_t n_perm, float *z_out, float *lag_out,
+                          float *I_out, int32_t *count_out, uint8_t *zero_var_out);
 /* Per-cell finalisation of the last sc_local_moran on the device (its z / lag / counts stay resident; count_out
  * above may then be null), replacing the p-value, FDR and quadrant passes of AC:888-934 over (n_cells x n_genes):
  * sc_local_moran_hist returns hist[g][c] = cells of gene g with permutation count c, c = 0..n_perm, from which the

@@ -58,7 +58,6 @@ SYMBOLS = {
     "sc_moran": [_P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_moran_seeded_begin": [_P, _P, c_int64, c_int64, c_int64],
-    "sc_moran_prepare_begin": [_P],
     "sc_moran_seeded_finish": [_P, _P, _P, _P, _P, _P, _P],
     "sc_moran_seeded_abort": [_P],
     "sc_lee": [_P, _P, _P, _P, c_int64, c_int64, _P, _P, _P],
@@ -66,6 +65,7 @@ SYMBOLS = {
     "sc_lee_shared": [_P, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P, _P],
     "sc_lee_observed_f32": [_P, _P, _P, c_int64, _P, _P, _P],
     "sc_local_moran": [_P, c_int64, c_int64, _P, _P, _P, _P, _P],
+    "sc_local_moran_seeded": [_P, _P, c_int64, _P, _P, _P, _P, _P],
     "sc_local_moran_hist": [_P, _P],
     "sc_local_moran_classify": [_P, _P, _P, _P, c_float, _P, _P, _P],
     "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
@@ -413,11 +413,6 @@ class Context:
         _check(self._lib.sc_moran_seeded_begin(self._h, _ptr(words), int(n_cells), int(n_perm), int(ahead_chunks)))
         self._begun_perms = int(n_perm)
 
-    def moran_prepare_begin(self) -> None:
-        """Expression and graph resident: enqueue the first half of the Moran preparation now (no wait), in front of the
-        generator launches of moran_seeded_begin."""
-        _check(self._lib.sc_moran_prepare_begin(self._h))
-
     def moran_seeded_abort(self) -> None:
         _check(self._lib.sc_moran_seeded_abort(self._h))
         self._begun_perms = 0
@@ -482,6 +477,20 @@ class Context:
         zero = np.zeros(G, dtype=np.uint8)
         _check(self._lib.sc_local_moran(self._h, int(n_perm), int(perm_row0), _ptr(z), _ptr(lag), _ptr(I), _ptr(cnt),
                                         _ptr(zero)))
+        return {"z": z, "lag": lag, "I": I, "count": cnt, "zero_var": zero.astype(bool)}
+
+    def local_moran_seeded(self, words: np.ndarray, n_cells: int, n_perm: int, fetch_counts: bool = True):
+        """local_moran with its n_perm permutations drawn from `words` (advanced in place) inside the call: generator and
+        per-cell counts run as one pipeline."""
+        G = self._n_genes
+        z = np.empty((n_cells, G), dtype=np.float32)
+        lag = np.empty((n_cells, G), dtype=np.float32)
+        I = np.empty((n_cells, G), dtype=np.float32)
+        cnt = np.zeros((n_cells, G), dtype=np.int32) if fetch_counts else None
+        zero = np.zeros(G, dtype=np.uint8)
+        _check(self._lib.sc_local_moran_seeded(self._h, _ptr(words), int(n_perm), _ptr(z), _ptr(lag), _ptr(I), _ptr(cnt),
+                                               _ptr(zero)))
+        self.permgen_note()
         return {"z": z, "lag": lag, "I": I, "count": cnt, "zero_var": zero.astype(bool)}
 
     def local_moran_hist(self, n_perm: int) -> np.ndarray:

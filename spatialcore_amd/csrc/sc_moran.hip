@@ -1250,9 +1250,10 @@ __global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ in
 // sum_j x[idx[j]] = sum_j x[j] behind the lattice form does not hold for them).
 // First half of moran_prepare: everything that needs neither a decision of the host nor the permutation count -- the
 // weight sum, the graph moments (side stream), the gene moments and value classes -- is enqueued, with its small results
-// on their way into pinned host memory, and NOTHING is waited for.  sc_moran_seeded_begin calls it in front of the
-// generator's launches when expression and graph are resident already (the generator takes ~10 ms of host time to
-// enqueue; the device works through this half meanwhile).  Any change of the expression or the graph drops it.
+// on their way into pinned host memory, and nothing is waited for.  (r03 measured this half ENQUEUED AHEAD of the
+// generator's launches for a resident expression -- the generator takes the host ~10 ms to enqueue -- : scoring started
+// at 19 ms instead of 31, but the generator's own first launches queued behind these full-chip kernels, its chain
+// started 4.5 ms later, and the step, which ends with the generator, was 1-2 ms LONGER.  Not kept; the split stays.)
 static int moran_prepare_early(sc_ctx *c)
 {
     const int64_t n = c->e_n, T = c->e_tiles;
@@ -1600,25 +1601,43 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
 #ifndef PIPE_FIRST
 #define PIPE_FIRST 32        // permutations of the first pipeline chunk
 #endif
-#ifndef PIPE_LAST
-#define PIPE_LAST 32         // ... of the last one (0: none in particular)
+#ifndef PIPE_TAIL
+#define PIPE_TAIL "96,48,24" // the last chunks, tapering: see pipe_tail_perms
 #endif
 #ifndef PIPE_SWAP_STREAMS
 #define PIPE_SWAP_STREAMS 2  // swap chunks in flight (they are latency-bound: two overlap almost for free)
 #endif
 
-// permutations of the pipeline's first / last chunk (SC_PIPE_FIRST / SC_PIPE_LAST: development, to sweep the schedule)
+// permutations of the pipeline's first chunk (SC_PIPE_FIRST: development, to sweep the schedule)
 static int64_t pipe_first_perms()
 {
     int64_t v = PIPE_FIRST;
     if (const char *e = getenv("SC_PIPE_FIRST")) v = atoi(e);
     return v < 8 || v > PERM_CHUNK ? PIPE_FIRST : v;
 }
-static int64_t pipe_last_perms()
+// The job ends with what is left once the generator's chain has finished: the swaps of its last chunk (~10 ms whatever
+// its size: one workgroup per permutation, latency-bound) and the consumption of every chunk not consumed yet.  Behind
+// a 128-permutation chunk that is its swaps AND its 10-ms consumption; tapering chunks leave a few milliseconds (bench
+// step, same box, ms: one 32-permutation last chunk 173.5 / 174.6; 64,32: 172.4 / 178.8; 64,32,16: 172.8 / 173.1; 96,48,24: 169.4 / 169.4).
+// SC_PIPE_TAIL="a,b,...": development, to sweep the schedule ("0": no short chunks at the end).
+static std::vector<int64_t> pipe_tail_perms()
 {
-    int64_t v = PIPE_LAST;
-    if (const char *e = getenv("SC_PIPE_LAST")) v = atoi(e);
-    return v < 0 || v > PERM_CHUNK ? PIPE_LAST : v;
+    const char *e = getenv("SC_PIPE_TAIL");
+    std::vector<int64_t> t;
+    for (const char *p = e ? e : PIPE_TAIL; *p;) {
+        char *end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        if (v >= 8 && v <= PERM_CHUNK) t.push_back(v);
+        p = *end == ',' ? end + 1 : end;
+    }
+    return t;
+}
+static int64_t pipe_tail_total()
+{
+    int64_t s = 0;
+    for (int64_t v : pipe_tail_perms()) s += v;
+    return s;
 }
 
 // The generator / consumer pipeline shared by sc_moran_seeded and sc_lee_seeded: numpy-exact permutation rows
@@ -1684,14 +1703,15 @@ static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_pe
     pp.bounds.clear();
     pp.bounds.push_back(0);
     if (n_perm > 3 * PERM_CHUNK) {
-        const int64_t first = pipe_first_perms(), last = pipe_last_perms();
+        const int64_t first = pipe_first_perms(), last = pipe_tail_total();
+        const std::vector<int64_t> tail = pipe_tail_perms();
         const int64_t rest = (n_perm - last - first) % PERM_CHUNK;
         static const bool join = getenv("SC_PIPE_JOIN") != nullptr;   // development: a small remainder joins the first chunk (r02 / early r03)
         int64_t p = first + (join && rest < PERM_CHUNK / 2 ? rest : 0);
         pp.bounds.push_back(p);
         if (p == first && rest > 0) { p += rest; pp.bounds.push_back(p); }   // the remainder: a chunk of its own, second
         for (; p < n_perm - last; ) { p += PERM_CHUNK; pp.bounds.push_back(p); }
-        if (last > 0) pp.bounds.push_back(n_perm);
+        for (int64_t v : tail) { p += v; pp.bounds.push_back(p); }
     } else {
         for (int64_t p = PERM_CHUNK; p < n_perm; p += PERM_CHUNK) pp.bounds.push_back(p);
         pp.bounds.push_back(n_perm);
@@ -1780,7 +1800,7 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
             int tail_prev = keep < 32 ? keep : 32, tail_last = 8;
             if (const char *v = getenv("SC_SCORE_LEAVE_TAIL")) sscanf(v, "%d,%d", &tail_prev, &tail_last);
             if (p1 == n_perm) c->score_leave_cus = tail_last;
-            else if (pipe_last_perms() > 0 && n_perm - p1 <= pipe_last_perms()) c->score_leave_cus = tail_prev;
+            else if (n_perm > 3 * PERM_CHUNK && n_perm - p1 < pipe_tail_total()) c->score_leave_cus = tail_prev;
         }
         const int rc = moran_perm_range(c, p0, p1, bits, false);
         c->score_leave_cus = keep;
@@ -1866,20 +1886,6 @@ extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t 
     if (rc != SC_OK) { delete pp; return rc; }
     c->pipe = pp;
     return SC_OK;
-}
-
-// For a caller whose expression and graph are resident BEFORE it begins the generator: enqueue the first half of the
-// preparation (graph and gene moments, value classes; see moran_prepare_early) now, in front of the generator's
-// launches -- these take the host ~10 ms to enqueue, the device works through this half meanwhile.  Optional: without
-// it sc_moran / sc_moran_seeded / _finish do the same work when they start.  Nothing is waited for.
-extern "C" int sc_moran_prepare_begin(sc_ctx *c)
-{
-    SC_REQUIRE(c, SC_ERR_INVALID, "null context");
-    SC_HIP(hipSetDevice(c->device));
-    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_moran_prepare_begin: no expression loaded");
-    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_moran_prepare_begin: graph missing or size mismatch");
-    if (c->prep_early) return SC_OK;
-    return moran_prepare_early(c);
 }
 
 extern "C" int sc_moran_seeded_abort(sc_ctx *c)
@@ -2497,14 +2503,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 3
     const uint4 *Y0 = Ys8 + (int64_t)grp * n * 8 + q;
     const float *zq = tz + q * LM_TAB_STRIDE;         // + b * 8 * LM_TAB_STRIDE + value
     const float *wq = (UNI ? tw : tz) + q * LM_TAB_STRIDE;
+    typedef float v2f __attribute__((ext_vector_type(2)));   // two genes per v_pk_add_f32 / v_pk_mul_f32: IEEE per component
     for (int p0 = 0; p0 < n_batch; p0 += LM_U8_QUAD) {
-        float s[LM_U8_QUAD][16];
+        v2f s[LM_U8_QUAD][8];
 #pragma unroll
         for (int p = 0; p < LM_U8_QUAD; ++p)
 #pragma unroll
-            for (int b = 0; b < 16; ++b) s[p][b] = 0.f;
+            for (int b = 0; b < 8; ++b) s[p][b] = (v2f){0.f, 0.f};
         for (long long e = e0; e < e1; ++e) {
             const float ww = w32[e];
+            const v2f ww2 = {ww, ww};
             const uint4 *Ye = Y0 + (int64_t)indices_r[e] * 8 + (int64_t)p0 * pstep;
             uint4 row[LM_U8_QUAD];
 #pragma unroll
@@ -2513,10 +2521,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 3
             for (int p = 0; p < LM_U8_QUAD; ++p) {
                 const uint32_t wd[4] = {row[p].x, row[p].y, row[p].z, row[p].w};
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const uint32_t v = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    const float term = UNI ? wq[b * 8 * LM_TAB_STRIDE + v] : __fmul_rn(ww, zq[b * 8 * LM_TAB_STRIDE + v]);
-                    s[p][b] = __fadd_rn(s[p][b], term);
+                for (int b = 0; b < 16; b += 2) {
+                    const uint32_t v0 = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu, v1 = (wd[b >> 2] >> (8 * (b & 3) + 8)) & 0xffu;
+                    v2f term = {wq[b * 8 * LM_TAB_STRIDE + v0], wq[(b + 1) * 8 * LM_TAB_STRIDE + v1]};
+                    if (!UNI) term = ww2 * term;          // (-ffp-contract=off: product and sum are rounded separately)
+                    s[p][b >> 1] = s[p][b >> 1] + term;
                 }
             }
         }
@@ -2526,9 +2535,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 3
                 const uint4 own = Y0[r * 8 + (int64_t)(p0 + p) * pstep];
                 const uint32_t wd[4] = {own.x, own.y, own.z, own.w};
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const uint32_t v = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    cnt[b >> 2] += (fabsf(__fmul_rn(zq[b * 8 * LM_TAB_STRIDE + v], s[p][b])) >= a[b] ? 1u : 0u) << (8 * (b & 3));
+                for (int b = 0; b < 16; b += 2) {
+                    const uint32_t v0 = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu, v1 = (wd[b >> 2] >> (8 * (b & 3) + 8)) & 0xffu;
+                    const v2f zi = {zq[b * 8 * LM_TAB_STRIDE + v0], zq[(b + 1) * 8 * LM_TAB_STRIDE + v1]};
+                    const v2f ip = zi * s[p][b >> 1];
+                    cnt[b >> 2] += (fabsf(ip.x) >= a[b] ? 1u : 0u) << (8 * (b & 3));
+                    cnt[b >> 2] += (fabsf(ip.y) >= a[b + 1] ? 1u : 0u) << (8 * (b & 3) + 8);
                 }
             }
         }
@@ -2579,22 +2591,25 @@ static bool lm_codes_ok(sc_ctx *c)
     return true;
 }
 
-extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
-                              float *I_out, int32_t *count_out, uint8_t *zero_var_out)
+// One local Moran job: the operands of the per-cell permutation counts (sc_local_moran, sc_local_moran_seeded)
+struct LmJob {
+    int64_t n = 0, G = 0, T = 0;
+    size_t tile_f = 0;
+    float *mean32 = nullptr, *sd32 = nullptr, *Z32 = nullptr, *I32 = nullptr, *Lag32 = nullptr;
+    int32_t *cnt = nullptr;
+    unsigned char *zero = nullptr;
+    dim3 gc;
+    int mode = 2;        // 0: one-kernel r01 form, 1: uint8 code rows, 2: float rows
+    int groups = 0;      // code rows: 128-gene groups
+    int64_t batch = 0;   // permutations per launch
+    bool uni = false;
+};
+
+// statistics in numpy's order, z, observed lag and I; then the form of the permutation counts and its buffers
+static int lm_prepare(sc_ctx *c, int64_t n_perm, LmJob &j)
 {
-    SC_REQUIRE(c && z_out && lag_out && I_out, SC_ERR_INVALID, "sc_local_moran: null pointer");
-    SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_local_moran: negative size");
-    SC_HIP(hipSetDevice(c->device));
-    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
-    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran: no expression loaded");
-    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran: graph missing or size mismatch");
-    c->lm_valid = false;
-    if (n_perm > 0) {
-        SC_REQUIRE(c->p_n == c->e_n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
-                   "sc_local_moran: needs permutation rows [%lld, %lld) of length %lld", (long long)perm_row0,
-                   (long long)(perm_row0 + n_perm), (long long)c->e_n);
-    }
     const int64_t n = c->e_n, G = c->e_genes, T = c->e_tiles;
+    c->lm_valid = false;
     const size_t tile_f = (size_t)T * n * SC_TILE;
     // per-gene mean and E[x^2] with numpy's own summation order, in the matrix dtype (see k_npc_*)
     SC_TRY(colsum<OP_NZ>(c, c->X.as<double>(), nullptr, c->g_Inum.as<double>(), 1.0));
@@ -2654,75 +2669,155 @@ extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, floa
     dim3 gc((unsigned)ceil_div64(n * 4, 256), (unsigned)T);
     hipLaunchKernelGGL(k_lm_observed, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                        c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, Lag32, I32, n);
-    if (n_perm > 0 && c->lm_direct) {   // r01 form (development A/B, sc_ctx_set_local_moran_direct)
-        KernelTimerScope ts(c, SC_K_LEE_PERM);
-        hipLaunchKernelGGL(k_lm_perm_count, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
-                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), Z32, I32,
-                           c->perm.as<int32_t>() + perm_row0 * c->p_stride, c->p_stride, (int)n_perm, cnt, n);
-    } else if (n_perm > 0 && lm_codes_ok(c)) {
+    SC_HIP(hipGetLastError());
+    j.n = n; j.G = G; j.T = T; j.tile_f = tile_f;
+    j.mean32 = mean32; j.sd32 = sd32; j.Z32 = Z32; j.I32 = I32; j.Lag32 = Lag32; j.cnt = cnt; j.zero = zero; j.gc = gc;
+    if (n_perm <= 0) return SC_OK;
+    if (c->lm_direct) { j.mode = 0; return SC_OK; }   // r01 form (development A/B, sc_ctx_set_local_moran_direct)
+    SC_TRY(sc_graph_ensure_order(c));
+    if (lm_codes_ok(c)) {
         // count data: the permuted matrix travels as uint8 code rows, z is looked up where it is used (k_lm_count_u8)
-        SC_TRY(sc_graph_ensure_order(c));
-        const int groups = (int)ceil_div64(T, 8);
-        const size_t row_bytes = (size_t)groups * (size_t)n * 128;
+        j.mode = 1;
+        j.groups = (int)ceil_div64(T, 8);
+        const size_t row_bytes = (size_t)j.groups * (size_t)n * 128;
         SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
-        SC_TRY(c->lm_tab.ensure(sizeof(float) * 2 * (size_t)groups * 128 * LM_TAB_STRIDE, &c->mem));
+        SC_TRY(c->lm_tab.ensure(sizeof(float) * 2 * (size_t)j.groups * 128 * LM_TAB_STRIDE, &c->mem));
         int64_t batch = (int64_t)(((size_t)4 << 30) / row_bytes) / LM_U8_QUAD * LM_U8_QUAD;
         batch = batch < LM_U8_QUAD ? LM_U8_QUAD : batch > LM_U8_BATCH_MAX ? LM_U8_BATCH_MAX : batch;
         if (batch > n_perm) batch = align_up64(n_perm, LM_U8_QUAD);
+        j.batch = batch;
         SC_TRY(c->lm_ys.ensure(row_bytes * (size_t)batch, &c->mem));
-        hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)groups), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)j.groups), dim3(256), 0, c->stream,
                            c->X.as<double>(), c->X32.as<uint4>(), n, T);
-        const bool uni = c->g_uniform_w > 0.0;
-        hipLaunchKernelGGL(k_lm_ztab, dim3((unsigned)ceil_div64((int64_t)groups * 128 * LM_TAB_STRIDE, 256)), dim3(256), 0, c->stream,
-                           mean32, sd32, T, uni ? (float)c->g_uniform_w : 0.f, c->lm_tab.as<float>(), groups);
-        KernelTimerScope ts(c, SC_K_LEE_PERM);
-        const dim3 g8((unsigned)ceil_div64(n * 8, 256), (unsigned)groups);
-        auto count_u8 = uni ? k_lm_count_u8<true> : k_lm_count_u8<false>;
-        for (int64_t p0 = 0; p0 < n_perm; p0 += batch) {
-            const int nb = (int)(n_perm - p0 < batch ? n_perm - p0 : batch);
+        j.uni = c->g_uniform_w > 0.0;
+        hipLaunchKernelGGL(k_lm_ztab, dim3((unsigned)ceil_div64((int64_t)j.groups * 128 * LM_TAB_STRIDE, 256)), dim3(256), 0, c->stream,
+                           mean32, sd32, T, j.uni ? (float)c->g_uniform_w : 0.f, c->lm_tab.as<float>(), j.groups);
+        SC_HIP(hipGetLastError());
+    } else {
+        j.mode = 2;
+        j.batch = LM_PERM_BATCH;
+        SC_TRY(c->lm_ys.ensure(sizeof(float) * (size_t)LM_PERM_BATCH * tile_f, &c->mem));
+    }
+    return SC_OK;
+}
+
+// counts of permutations [p0, p1) of the job (rows row0 + p of the forward table); p0 == 0 starts the counts
+static int lm_count(sc_ctx *c, const LmJob &j, int64_t row0, int64_t p0, int64_t p1)
+{
+    const int64_t n = j.n, T = j.T;
+    if (p1 <= p0) return SC_OK;
+    KernelTimerScope ts(c, SC_K_LEE_PERM);
+    if (j.mode == 0) {
+        SC_REQUIRE(p0 == 0, SC_ERR_STATE, "internal: the one-kernel local Moran form counts all permutations at once");
+        hipLaunchKernelGGL(k_lm_perm_count, j.gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                           c->g_indices.as<int32_t>(), c->g_data.as<double>(), j.Z32, j.I32,
+                           c->perm.as<int32_t>() + row0 * c->p_stride, c->p_stride, (int)(p1 - p0), j.cnt, n);
+    } else if (j.mode == 1) {
+        const dim3 g8((unsigned)ceil_div64(n * 8, 256), (unsigned)j.groups);
+        auto count_u8 = j.uni ? k_lm_count_u8<true> : k_lm_count_u8<false>;
+        for (int64_t p = p0; p < p1; p += j.batch) {
+            const int nb = (int)(p1 - p < j.batch ? p1 - p : j.batch);
             hipLaunchKernelGGL(k_lm_gather_u8, dim3(g8.x, g8.y, (unsigned)nb), dim3(256), 0, c->stream, c->X32.as<uint4>(),
-                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (perm_row0 + p0) * c->p_stride, c->p_stride,
-                               n, groups, c->lm_ys.as<uint4>());
+                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (row0 + p) * c->p_stride, c->p_stride,
+                               n, j.groups, c->lm_ys.as<uint4>());
             hipLaunchKernelGGL(count_u8, g8, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                                c->g_indices_r.as<int32_t>(), c->g_w32.as<float>(), c->g_order.as<int32_t>(),
-                               c->lm_ys.as<uint4>(), I32, c->lm_tab.as<float>(), nb, T, groups, cnt, n, p0 == 0 ? 1 : 0);
+                               c->lm_ys.as<uint4>(), j.I32, c->lm_tab.as<float>(), nb, T, j.groups, j.cnt, n, p == 0 ? 1 : 0);
         }
-    } else if (n_perm > 0) {
-        SC_TRY(sc_graph_ensure_order(c));
-        SC_TRY(c->lm_ys.ensure(sizeof(float) * (size_t)LM_PERM_BATCH * tile_f, &c->mem));
-        KernelTimerScope ts(c, SC_K_LEE_PERM);
-        for (int64_t p0 = 0; p0 < n_perm; p0 += LM_PERM_BATCH) {
-            const int nb = (int)(n_perm - p0 < LM_PERM_BATCH ? n_perm - p0 : LM_PERM_BATCH);
-            hipLaunchKernelGGL(k_lm_gather_sorted, dim3(gc.x, (unsigned)T, (unsigned)nb), dim3(256), 0, c->stream, Z32,
-                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (perm_row0 + p0) * c->p_stride, c->p_stride,
+    } else {
+        for (int64_t p = p0; p < p1; p += j.batch) {
+            const int nb = (int)(p1 - p < j.batch ? p1 - p : j.batch);
+            hipLaunchKernelGGL(k_lm_gather_sorted, dim3(j.gc.x, (unsigned)T, (unsigned)nb), dim3(256), 0, c->stream, j.Z32,
+                               c->g_order.as<int32_t>(), c->perm.as<int32_t>() + (row0 + p) * c->p_stride, c->p_stride,
                                n, T, c->lm_ys.as<float>());
-            hipLaunchKernelGGL(k_lm_count_sorted, gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+            hipLaunchKernelGGL(k_lm_count_sorted, j.gc, dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
                                c->g_indices_r.as<int32_t>(), c->g_w32.as<float>(), c->g_order.as<int32_t>(),
-                               c->lm_ys.as<float>(), I32, nb, T, cnt, n, p0 == 0 ? 1 : 0);
+                               c->lm_ys.as<float>(), j.I32, nb, T, j.cnt, n, p == 0 ? 1 : 0);
         }
     }
     SC_HIP(hipGetLastError());
-    // un-tile into row-major (cells x genes) staging and copy back
+    return SC_OK;
+}
+
+// un-tile into row-major (cells x genes) staging and copy back
+static int lm_finish(sc_ctx *c, const LmJob &j, int64_t n_perm, float *z_out, float *lag_out, float *I_out,
+                     int32_t *count_out, uint8_t *zero_var_out)
+{
+    const int64_t n = j.n, G = j.G;
     SC_TRY(c->lee_a.ensure(sizeof(float) * (size_t)n * (size_t)G, &c->mem));
     unsigned gu = (unsigned)ceil_div64(n * G, 256);
-    struct { const float *src; float *dst; } outs[3] = {{Z32, z_out}, {Lag32, lag_out}, {I32, I_out}};
+    struct { const float *src; float *dst; } outs[3] = {{j.Z32, z_out}, {j.Lag32, lag_out}, {j.I32, I_out}};
     for (auto &o : outs) {
         hipLaunchKernelGGL(k_untile<float>, dim3(gu), dim3(256), 0, c->stream, o.src, c->lee_a.as<float>(), n, G);
         SC_HIP(hipMemcpyAsync(o.dst, c->lee_a.p, sizeof(float) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
                               c->stream));
     }
     if (n_perm > 0 && count_out) {
-        hipLaunchKernelGGL(k_untile<int32_t>, dim3(gu), dim3(256), 0, c->stream, cnt, c->lee_a.as<int32_t>(), n, G);
+        hipLaunchKernelGGL(k_untile<int32_t>, dim3(gu), dim3(256), 0, c->stream, j.cnt, c->lee_a.as<int32_t>(), n, G);
         SC_HIP(hipMemcpyAsync(count_out, c->lee_a.p, sizeof(int32_t) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
                               c->stream));
     }
     if (zero_var_out)
-        SC_HIP(hipMemcpyAsync(zero_var_out, zero, (size_t)G, hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipMemcpyAsync(zero_var_out, j.zero, (size_t)G, hipMemcpyDeviceToHost, c->stream));
     SC_HIP(hipGetLastError());
     SC_HIP(hipStreamSynchronize(c->stream));
     c->lm_valid = true;  // z / lag / counts stay resident for sc_local_moran_hist / sc_local_moran_classify
     c->lm_perms = n_perm;
     return SC_OK;
+}
+
+extern "C" int sc_local_moran(sc_ctx *c, int64_t n_perm, int64_t perm_row0, float *z_out, float *lag_out,
+                              float *I_out, int32_t *count_out, uint8_t *zero_var_out)
+{
+    SC_REQUIRE(c && z_out && lag_out && I_out, SC_ERR_INVALID, "sc_local_moran: null pointer");
+    SC_REQUIRE(n_perm >= 0 && perm_row0 >= 0, SC_ERR_INVALID, "sc_local_moran: negative size");
+    SC_HIP(hipSetDevice(c->device));
+    if (n_perm > 0) SC_TRY(sc_perm_forward_ensure(c));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran: graph missing or size mismatch");
+    c->lm_valid = false;
+    if (n_perm > 0) {
+        SC_REQUIRE(c->p_n == c->e_n && perm_row0 + n_perm <= c->p_count, SC_ERR_STATE,
+                   "sc_local_moran: needs permutation rows [%lld, %lld) of length %lld", (long long)perm_row0,
+                   (long long)(perm_row0 + n_perm), (long long)c->e_n);
+    }
+    LmJob j;
+    SC_TRY(lm_prepare(c, n_perm, j));
+    SC_TRY(lm_count(c, j, perm_row0, 0, n_perm));
+    return lm_finish(c, j, n_perm, z_out, lag_out, I_out, count_out, zero_var_out);
+}
+
+// The same with the permutations drawn here: n_perm numpy-exact permutations of the cells from state6 (as
+// sc_perm_generate would draw them; state6 is advanced the same way, the table stays resident), generated chunk
+// by chunk while the per-cell counts of the finished chunks are taken -- the generator's chain is the longest part of
+// a local Moran call, and the counts hide behind it.  Same outputs as sc_perm_generate + sc_local_moran.
+extern "C" int sc_local_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm, float *z_out, float *lag_out,
+                                     float *I_out, int32_t *count_out, uint8_t *zero_var_out)
+{
+    SC_REQUIRE(c && state6 && z_out && lag_out && I_out, SC_ERR_INVALID, "sc_local_moran_seeded: null pointer");
+    SC_REQUIRE(n_perm >= 1 && n_perm <= (1 << 24), SC_ERR_INVALID, "sc_local_moran_seeded: n_perm=%lld out of range", (long long)n_perm);
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_local_moran_seeded: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran_seeded: graph missing or size mismatch");
+    c->lm_valid = false;
+    LmJob j;
+    auto prepare = [&]() -> int { return lm_prepare(c, n_perm, j); };
+    auto count = [&](int64_t p0, int64_t p1) -> int {
+        if (j.mode == 0) return p1 == n_perm ? lm_count(c, j, 0, 0, n_perm) : SC_OK;   // (the one-kernel form: all rows at the end)
+        return lm_count(c, j, 0, p0, p1);
+    };
+    const int ahead = c->pg_ahead;
+    c->pg_ahead = 2;
+    int rc = sc_perm_pipeline(c, state6, c->e_n, n_perm, 0, prepare, count);
+    if (rc == SC_PERMGEN_RETRY) {   // the block-parallel scan failed its verification: the counts restart at permutation 0
+        const int mode = c->pg_mode;
+        c->pg_mode = 1;
+        rc = sc_perm_pipeline(c, state6, c->e_n, n_perm, 0, prepare, count);
+        c->pg_mode = mode;
+    }
+    c->pg_ahead = ahead;
+    SC_TRY(rc);
+    return lm_finish(c, j, n_perm, z_out, lag_out, I_out, count_out, zero_var_out);
 }
 
 // hist[gene][c] = cells of the gene with permutation count c (LDS-private per workgroup while 16 genes' worth fits)

@@ -1658,6 +1658,17 @@ extern "C" int sc_perm_generate_counter(sc_ctx *c, uint64_t seed, int64_t n, int
 
 static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm)
 {
+    if (permgen_is_block_parallel(c, n) && n_perm > 3 * PERM_CHUNK) {
+        // a long job: the chunked pipeline of the seeded statistics with nothing to consume -- the Fisher-Yates swaps of
+        // chunk k run (on their own streams) beside the rejection scan of chunk k + 1 instead of all behind the scan
+        // (r03, 999 permutations of 1M cells: 55 ms of swaps out of the call's critical path)
+        const int ahead = c->pg_ahead;
+        c->pg_ahead = 2;
+        const int rc = sc_perm_pipeline(c, state6, n, n_perm, 0, nullptr, [](int64_t, int64_t) -> int { return SC_OK; });
+        c->pg_ahead = ahead;
+        if (rc == SC_OK) c->perm_forward_valid = true;
+        return rc;
+    }
     PermJob job;
     SC_TRY(permgen_begin(c, state6, n, n_perm, &job, c->stream));
     for (int64_t p0 = 0; p0 < n_perm; p0 += PERM_CHUNK) {

@@ -638,9 +638,10 @@ def local_morans_i(
             ctx.set_expression(X[:, cols], np.arange(cols.size, dtype=np.int32))
         else:
             ctx.set_expression(X, cols.astype(np.int32))
-        if n_permutations > 0:
-            ctx.generate_permutations(words, n_cells, n_permutations)  # continues the one stream
-        r = ctx.local_moran(n_cells, n_permutations, fetch_counts=False)
+        if n_permutations > 0:   # continues the one stream; generator and per-cell counts run as one pipeline
+            r = ctx.local_moran_seeded(words, n_cells, n_permutations, fetch_counts=False)
+        else:
+            r = ctx.local_moran(n_cells, 0, fetch_counts=False)
         zero = r["zero_var"]
         # per-cell p, adjusted p and quadrants on the device: lookup tables per (gene, permutation count) built here
         # with the reference's expressions (AC:894-896, 912-920); zero-variance genes get p = p_adj = 1, quadrant 0

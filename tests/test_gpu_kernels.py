@@ -646,6 +646,35 @@ def test_local_moran_code_rows_equal_float_rows(ctx, monkeypatch, uniform):
         np.testing.assert_array_equal(a["count"], b["count"])
 
 
+@pytest.mark.parametrize("n,P,counts", [(3000, 41, True), (140_000, 150, True), (140_000, 37, False)])
+def test_local_moran_seeded_equals_generate_then_count(ctx, n, P, counts):
+    """sc_local_moran_seeded draws its permutations inside the call, chunk by chunk beside the per-cell counts (block-parallel
+    generator from 131072 cells on): outputs, counts and the advanced generator state must be those of
+    sc_perm_generate followed by sc_local_moran -- for count data (uint8 code rows) and for non-integer data (float
+    rows)."""
+    from spatialcore_amd._lib import rng_state_words
+
+    G, k = 21, 6
+    rng = np.random.default_rng(n + P)
+    coords = rng.uniform(0, np.sqrt(n) * 10, (n, 2))
+    X = rng.poisson(rng.uniform(0.1, 3.0, G), (n, G)).astype(np.float32)
+    if not counts:
+        X *= np.float32(0.37)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    ctx.set_expression(X, np.arange(G))
+    fallbacks = ctx.permgen_stats()[2]
+    w1 = rng_state_words(np.random.default_rng(77))
+    ctx.generate_permutations(w1, n, P)
+    want = ctx.local_moran(n, P)
+    w2 = rng_state_words(np.random.default_rng(77))
+    got = ctx.local_moran_seeded(w2, n, P)
+    np.testing.assert_array_equal(w1, w2)
+    for f in ("z", "lag", "I", "count"):
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    assert ctx.permgen_stats()[2] == fallbacks    # no verification fallback
+
+
 def test_lee_vs_reference_golden(ctx, oracle):
     from spatialcore_amd._lib import rng_state_words
 
