@@ -103,6 +103,11 @@ int sc_ctx_permgen_stats(sc_ctx *ctx, int64_t *jobs_parallel, int64_t *jobs_sequ
  * turned into the active graph with sc_graph_from_knn. */
 int sc_knn_2d(sc_ctx *ctx, const double *xy, int64_t n, int k, int include_self,
               int32_t *idx_out, double *rdist_out);
+/* The neighbour lists of the last sc_knn_2d that was called WITHOUT output arrays (it then returns without waiting),
+ * copied out on a stream of their own: neither behind the work the context has been given since, nor in its way.  For a
+ * caller that fetches the lists (squidpy's obsp side effects, AC:565-570) from one thread while another uploads the
+ * expression.  Either pointer may be null. */
+int sc_knn_fetch(sc_ctx *ctx, int32_t *idx_out, double *rdist_out);
 
 /* ---- A2: radius graph ---------------------------------------------------------------------
  * Replaces cKDTree.query_ball_point(coords, r) with self removed (NB:241-244): closed ball

@@ -40,6 +40,7 @@ SYMBOLS = {
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
     "sc_debug_copy": [_P, c_int, c_int64, _P, c_int64],
     "sc_knn_2d": [_P, _P, c_int64, c_int, c_int, _P, _P],
+    "sc_knn_fetch": [_P, _P, _P],
     "sc_radius_count_2d": [_P, _P, c_int64, c_double, _P],
     "sc_radius_fill_2d": [_P, c_int64, _P],
     "sc_graph_set_csr": [_P, _P, _P, _P, c_int64, c_int64],
@@ -282,6 +283,16 @@ class Context:
         rd = np.empty((n, k), dtype=np.float64) if (return_distance and fetch) else None
         self._xy_in_flight = xy      # fetch=False returns without waiting: the upload may still be reading this array
         _check(self._lib.sc_knn_2d(self._h, _ptr(xy), n, int(k), int(include_self), _ptr(idx), _ptr(rd)))
+        self._knn_shape = (n, int(k))
+        return (idx, rd) if return_distance else idx
+
+    def knn_fetch(self, return_distance: bool = True):
+        """Neighbour lists of the last knn(..., fetch=False), copied out on the library's copy stream (callable from a
+        second thread while the context's stream works on something else)."""
+        n, k = self._knn_shape
+        idx = np.empty((n, k), dtype=np.int32)
+        rd = np.empty((n, k), dtype=np.float64) if return_distance else None
+        _check(self._lib.sc_knn_fetch(self._h, _ptr(idx), _ptr(rd)))
         return (idx, rd) if return_distance else idx
 
     def radius_graph(self, coords, radius: float):

@@ -376,8 +376,29 @@ extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int incl
     // nothing to hand back: the result stays on the device and every consumer is ordered behind it on the context's
     // stream, so the host need not wait (the caller's coordinate array has been staged by the pageable-memory copy)
     if (idx_out || rdist_out) SC_HIP(hipStreamSynchronize(c->stream));
+    else {   // for a later sc_knn_fetch on the copy stream
+        if (!c->knn_done) SC_HIP(hipEventCreateWithFlags(&c->knn_done, hipEventDisableTiming));
+        SC_HIP(hipEventRecord(c->knn_done, c->stream));
+    }
     c->knn_n = n;
     c->knn_k = k;
+    return SC_OK;
+}
+
+// The result of the last sc_knn_2d that was called without output arrays, copied out on a stream of its own (ordered
+// behind the search by an event): the copy neither waits for what the context's stream has been given since, nor holds
+// it up -- a caller's thread can fetch the neighbour lists while another uploads the expression (PCIe is full duplex).
+extern "C" int sc_knn_fetch(sc_ctx *c, int32_t *idx_out, double *rdist_out)
+{
+    SC_REQUIRE(c, SC_ERR_INVALID, "sc_knn_fetch: null context");
+    SC_REQUIRE(c->knn_n > 0 && c->knn_done, SC_ERR_STATE, "sc_knn_fetch: no resident kNN result (sc_knn_2d without output arrays first)");
+    SC_HIP(hipSetDevice(c->device));
+    if (!c->stream_copy) SC_HIP(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    const size_t nk = (size_t)c->knn_n * (size_t)c->knn_k;
+    SC_HIP(hipStreamWaitEvent(c->stream_copy, c->knn_done, 0));
+    if (idx_out) SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * nk, hipMemcpyDeviceToHost, c->stream_copy));
+    if (rdist_out) SC_HIP(hipMemcpyAsync(rdist_out, c->knn_rd.p, sizeof(double) * nk, hipMemcpyDeviceToHost, c->stream_copy));
+    SC_HIP(hipStreamSynchronize(c->stream_copy));
     return SC_OK;
 }
 

@@ -168,6 +168,13 @@ def _knn_device_graph(ctx, coords, n_neighbors: int):
     return idx, rd
 
 
+def _knn_device_graph_async(ctx, coords, n_neighbors: int) -> None:
+    """The same without waiting and without fetching: search and graph are enqueued, the neighbour lists stay on the
+    device for ``ctx.knn_fetch()``."""
+    ctx.knn(coords, n_neighbors, fetch=False)
+    ctx.graph_from_knn(1.0 / n_neighbors)
+
+
 def _record_squidpy_neighbors(adata, idx, rd, n_neighbors: int) -> None:
     """Host half: what ``sq.gr.spatial_neighbors(adata, n_neighs=k, coord_type='generic')`` leaves behind
     (AC:565-570) [upstream squidpy]: binary float64 connectivities + euclidean distances in ``adata.obsp`` and a
@@ -369,7 +376,8 @@ def _morans_i_on_device(adata, ctx, coords, gene_names, layer, n_neighbors, n_pe
                                                      "transform": None}}
     else:
         logger.debug(f"Building spatial neighbors graph (k={n_neighbors})")
-        knn_found = _knn_device_graph(ctx, coords, n_neighbors)
+        _knn_device_graph_async(ctx, coords, n_neighbors)   # enqueued; the lists are fetched beside the upload below
+        knn_found = True
 
     cols, where = _unique_columns(adata, gene_names)
     # Genes are scored in batches that fit the device (four tile sets of n_cells x 8 bytes per gene, ~1/2 of the HBM
@@ -387,15 +395,16 @@ def _morans_i_on_device(adata, ctx, coords, gene_names, layer, n_neighbors, n_pe
         else:
             upload = lambda: ctx.set_expression(X, part)
         if knn_found is not None:
-            # the first batch's upload (PCIe) runs beside the host-side assembly of squidpy's obsp / uns side effects
-            _beside(upload, lambda: _record_squidpy_neighbors(adata, knn_found[0], knn_found[1], n_neighbors))
+            # the first batch's upload (PCIe, host -> device) runs beside the fetch of the neighbour lists (device -> host,
+            # on the library's copy stream) and the host-side assembly of squidpy's obsp / uns side effects
+            _beside(upload, lambda: _record_squidpy_neighbors(adata, *ctx.knn_fetch(), n_neighbors))
             knn_found = None
         else:
             upload()
         res = _moran_resident(ctx, n_cells, n_permutations, seed, reuse_table=b0 > 0, begun=begun if b0 == 0 else None)
         score[b0:b0 + per_batch], p_all[b0:b0 + per_batch] = res["I"], res["p_value"]
     if knn_found is not None:   # (no gene batch ran)
-        _record_squidpy_neighbors(adata, knn_found[0], knn_found[1], n_neighbors)
+        _record_squidpy_neighbors(adata, *ctx.knn_fetch(), n_neighbors)
     var_norm, expected_I = res["var_norm"], res["expected_I"]
 
     results = []
