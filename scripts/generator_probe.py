@@ -5,6 +5,8 @@ import numpy as np
 from spatialcore_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+if os.environ.get("SC_LIB"):   # another build of the library (e.g. spatialcore_amd/libvar_phiprofile.so)
+    _lib.LIB_PATH = os.environ["SC_LIB"]
 ctx = _lib.Context(0)
 for rep in range(3):
     w = _lib.rng_state_words(np.random.default_rng(0))
@@ -14,6 +16,13 @@ for rep in range(3):
     print(f"{P} x {N}: {dt * 1e3:.1f} ms, stats {ctx.permgen_stats()}, state {w[:2]}", flush=True)
 st = ctx.debug_copy(5, 0, 8, np.uint64)
 if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE
+    prof = ctx.debug_copy(100, 0, 32, np.uint64)
+    names = ["> 98304 steps left (band changes, window misses)", "49152 .. 98304", "24576 .. 49152", "12288 .. 24576", "<= 12288 (the permutation ends inside)"]
+    jobs = 3 * P
+    for k, nm in enumerate(names):
+        cnt, clk, rounds = int(prof[4 * k]), int(prof[4 * k + 1]), int(prof[4 * k + 2])
+        if cnt:
+            print(f"computed blocks with {nm}: {cnt / jobs:.2f} per permutation, {clk / cnt:.0f} clocks and {rounds / cnt:.1f} rounds each, {clk / jobs:.0f} clocks per permutation")
     easy, hard = 64 * (int(st[6]) & 0xffffffff), 64 * (int(st[6]) >> 32)
     print(f"chain clocks of the last job: lookup phases {easy / 1e6:.1f}M = {easy / max(int(st[4]), 1):.0f} per block, {easy / max(int(st[7]), 1):.0f} per pass "
           f"({int(st[7])} passes); computed blocks {hard / 1e6:.1f}M = {hard / max(int(st[5]), 1):.0f} each")

@@ -215,6 +215,10 @@ int sc_debug_copy(sc_ctx *c, int which, int64_t offset, void *out, int64_t bytes
 {
     SC_REQUIRE(c && out && offset >= 0 && bytes >= 0, SC_ERR_INVALID, "sc_debug_copy: bad argument");
     SC_HIP(hipSetDevice(c->device));
+    if (which == 100) {   // development builds of the generator (-DPHI_PROFILE): 32 words, reset when offset != 0
+        SC_REQUIRE(bytes == 32 * (int64_t)sizeof(unsigned long long), SC_ERR_INVALID, "sc_debug_copy: the generator profile is 32 words");
+        return sc_permgen_profile(reinterpret_cast<unsigned long long *>(out), offset != 0);
+    }
     const DBuf *bufs[] = {&c->pg_J, &c->pg_raw, &c->pg_bits, &c->pg_enter, &c->pg_sblk, &c->pg_out, &c->perm, &c->inv};
     SC_REQUIRE(which >= 0 && which < (int)(sizeof(bufs) / sizeof(bufs[0])), SC_ERR_INVALID, "sc_debug_copy: unknown buffer %d", which);
     const DBuf *b = bufs[which];

@@ -224,6 +224,7 @@ int sc_perm_forward_ensure(sc_ctx *c);  // materialise c->perm from c->inv after
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);
 int sc_perm_alloc(sc_ctx *c, int64_t n, int64_t n_perm);
 // generator / consumer pipeline (sc_moran.hip): table 0 = permutation rows, 1 = inverse rows only, 2 = both
+int sc_permgen_profile(unsigned long long *out32, int reset);   // development builds (-DPHI_PROFILE): computed blocks by class
 int sc_perm_pipeline(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_perm, int table,
                      const std::function<int()> &after_first, const std::function<int(int64_t, int64_t)> &score);
 

@@ -299,7 +299,8 @@ __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t x)
 // Returns 1 if the iteration cap was hit (cannot happen: the prefix grows by at least one thread a round).
 __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], uint64_t S_block,
                                                  uint32_t rem_block, uint32_t M, uint32_t top_mask, uint64_t total_steps, BlockShared &sh,
-                                                 uint32_t &parity, ScanRes &r, uint32_t &excl, uint32_t &total_cnt)
+                                                 uint32_t &parity, ScanRes &r, uint32_t &excl, uint32_t &total_cnt,
+                                                 int *rounds_out = nullptr)
 {
     // rem_block = M - S_block % M, the steps left in the current permutation (callers carry it along: a
     // 64-bit modulo per block by every wavefront costs more than a fifth of the block)
@@ -324,7 +325,10 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         total_cnt = (uint32_t)__builtin_amdgcn_readlane((int)run, NW - 1);
         const uint32_t before = wave ? (uint32_t)__builtin_amdgcn_readlane((int)run, wave - 1) : 0u;
         excl = before + incl - r.cnt;
-        if (!anybody) return 0;   // the counts are those of the previous round, in which every cached result was valid
+        if (!anybody) {           // the counts are those of the previous round, in which every cached result was valid
+            if (rounds_out) *rounds_out = iter + 1;
+            return 0;
+        }
         const bool stale = !scan_still_valid(r, excl, M, limit);
         recomputed = __any(stale) ? 1u : 0u;
         if (recomputed) {
@@ -806,6 +810,22 @@ static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
     return SC_OK;
 }
 
+#ifdef PHI_PROFILE
+__device__ unsigned long long g_phi_prof[32];   // development: see k_chain (read by sc_permgen_profile)
+int sc_permgen_profile(unsigned long long *out32, int reset)
+{
+    SC_HIP(hipDeviceSynchronize());
+    SC_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phi_prof), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {};
+        SC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phi_prof), z, sizeof(z)));
+    }
+    return SC_OK;
+}
+#else
+int sc_permgen_profile(unsigned long long *out32, int) { memset(out32, 0, sizeof(unsigned long long) * 32); return SC_OK; }
+#endif
+
 // Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
 // wavefront 0, the others the full in-block fixed point.  While a block is computed, the draws of the next
 // block to compute and the tables of the run of prepared blocks before it are already on their way (registers,
@@ -1071,7 +1091,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
         ScanRes r;
         uint32_t excl, total_cnt;
+#ifdef PHI_PROFILE
+        const uint32_t pf_rem = rem;
+        int pf_rounds = 0;
+        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, &pf_rounds) > 0) { failed = 1; rel = x; break; }
+        if (tau == 0) {   // computed blocks by the steps left in their permutation: count, clocks of the fixed point, rounds
+            const int cls = pf_rem > 98304u ? 0 : pf_rem > 49152u ? 1 : pf_rem > 24576u ? 2 : pf_rem > 12288u ? 3 : 4;
+            atomicAdd(&g_phi_prof[cls * 4], 1ull);
+            atomicAdd(&g_phi_prof[cls * 4 + 1], (unsigned long long)(clock64() - pf_t1));
+            atomicAdd(&g_phi_prof[cls * 4 + 2], (unsigned long long)pf_rounds);
+        }
+#else
         if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; rel = x; break; }
+#endif
         const uint64_t bx = b0 + x;
         acc_bits[bx * SCAN_THREADS + tau] = r.bits;
         enter[bx * SCAN_THREADS + tau] = excl;
