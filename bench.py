@@ -461,8 +461,9 @@ def main() -> None:
                                       + (" [file transport, rehearsal]" if rehearse else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "kernel_forms": "k_moran_score_wg (chunks of 128 permutations) + k_moran_score "
-                                                                "(the pipeline's short first / last chunk); same arithmetic",
+                         "kernel": kernel_name, "kernel_forms": "k_moran_score_wg (every chunk of the pipeline's schedule: 32, remainder, 128 x k, "
+                                                                "96, 48, 24 permutations; a chunk whose last task holds fewer than 24 would "
+                                                                "take k_moran_score); same arithmetic; the average is over all launches",
                          "avg_launch_ms": avg_ms, "launches": perm_launches,
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "step_frac": rf["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -668,6 +668,16 @@ class RcclComm:
 _default_ctx = {}
 
 
+def release_default_contexts() -> None:
+    """Destroy the cached per-device contexts (their device memory and streams); the next default_context() creates anew.
+    A process's streams share hardware queues once they outnumber GPU_MAX_HW_QUEUES, so a program that is done with the
+    default context and goes on with contexts of its own (the test suite) gives it back."""
+    for ctx in list(_default_ctx.values()):
+        if ctx is not None and ctx._h is not None:
+            ctx.close()
+    _default_ctx.clear()
+
+
 def default_context(device: int = 0) -> Context:
     """Process-wide context per device (created on first use; raises without a gfx950 GPU)."""
     ctx = _default_ctx.get(device)

@@ -164,7 +164,6 @@ int sc_ctx_destroy(sc_ctx *c)
     if (c->mom_ready) (void)hipEventDestroy(c->mom_ready);
     if (c->mom_done) (void)hipEventDestroy(c->mom_done);
     if (c->stream_m) (void)hipStreamDestroy(c->stream_m);
-    if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
     if (c->knn_done) (void)hipEventDestroy(c->knn_done);
     (void)hipStreamSynchronize(c->stream);
     DBuf *bufs[] = {&c->px, &c->py, &c->sx, &c->sy, &c->sid, &c->bin_start, &c->bin_keys,

@@ -95,7 +95,6 @@ struct sc_ctx {
     int knn_k = 0;
     DBuf knn_idx, knn_rd;  // [n][k] device result of the last sc_knn_2d
     hipEvent_t knn_done = nullptr;      // ... recorded behind a search whose result was not fetched (sc_knn_fetch)
-    hipStream_t stream_copy = nullptr;  // sc_knn_fetch's own stream
     DBuf knn_hd, knn_hi;   // k > 32: the per-query candidate heaps, [slot][query]
     double radius = -1.0;
     DBuf rad_indptr;  // [n+1] int64 of the last radius count

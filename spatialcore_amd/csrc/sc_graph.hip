@@ -385,7 +385,7 @@ extern "C" int sc_knn_2d(sc_ctx *c, const double *xy, int64_t n, int k, int incl
     return SC_OK;
 }
 
-// The result of the last sc_knn_2d that was called without output arrays, copied out on a stream of its own (ordered
+// The result of the last sc_knn_2d that was called without output arrays, copied out on the context's side stream (ordered
 // behind the search by an event): the copy neither waits for what the context's stream has been given since, nor holds
 // it up -- a caller's thread can fetch the neighbour lists while another uploads the expression (PCIe is full duplex).
 extern "C" int sc_knn_fetch(sc_ctx *c, int32_t *idx_out, double *rdist_out)
@@ -393,12 +393,15 @@ extern "C" int sc_knn_fetch(sc_ctx *c, int32_t *idx_out, double *rdist_out)
     SC_REQUIRE(c, SC_ERR_INVALID, "sc_knn_fetch: null context");
     SC_REQUIRE(c->knn_n > 0 && c->knn_done, SC_ERR_STATE, "sc_knn_fetch: no resident kNN result (sc_knn_2d without output arrays first)");
     SC_HIP(hipSetDevice(c->device));
-    if (!c->stream_copy) SC_HIP(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    // the side stream of the graph moments serves as the copy stream (a stream more per context would be a hardware queue
+    // more: a process whose streams outnumber GPU_MAX_HW_QUEUES has them share queues, which the generator must avoid)
+    sc_graph_moments_drain(c);
+    if (!c->stream_m) SC_HIP(hipStreamCreateWithFlags(&c->stream_m, hipStreamNonBlocking));
     const size_t nk = (size_t)c->knn_n * (size_t)c->knn_k;
-    SC_HIP(hipStreamWaitEvent(c->stream_copy, c->knn_done, 0));
-    if (idx_out) SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * nk, hipMemcpyDeviceToHost, c->stream_copy));
-    if (rdist_out) SC_HIP(hipMemcpyAsync(rdist_out, c->knn_rd.p, sizeof(double) * nk, hipMemcpyDeviceToHost, c->stream_copy));
-    SC_HIP(hipStreamSynchronize(c->stream_copy));
+    SC_HIP(hipStreamWaitEvent(c->stream_m, c->knn_done, 0));
+    if (idx_out) SC_HIP(hipMemcpyAsync(idx_out, c->knn_idx.p, sizeof(int32_t) * nk, hipMemcpyDeviceToHost, c->stream_m));
+    if (rdist_out) SC_HIP(hipMemcpyAsync(rdist_out, c->knn_rd.p, sizeof(double) * nk, hipMemcpyDeviceToHost, c->stream_m));
+    SC_HIP(hipStreamSynchronize(c->stream_m));
     return SC_OK;
 }
 

@@ -15,7 +15,7 @@ K = 15
 
 @pytest.fixture(scope="module")
 def big():
-    from spatialcore_amd._lib import Context
+    from spatialcore_amd import _lib
 
     rng = np.random.default_rng(42)
     coords = rng.uniform(0, np.sqrt(N) * 10.0, (N, 2))
@@ -23,8 +23,7 @@ def big():
     lam = np.exp(rng.uniform(np.log(0.05), np.log(5.0), G))
     X = rng.poisson(lam, (N, G)).astype(np.float32)
     X[:, ::2] += (2.0 * (1 + np.sin(coords[:, :1] / 900.0))).astype(np.float32)   # spatially smooth genes
-    with Context(0) as ctx:
-        yield ctx, coords, X
+    yield _lib.default_context(0), coords, X   # (one context per process: see tests/test_gpu_kernels.py::ctx)
 
 
 def test_knn_1m_spot_check_against_tree(big, oracle):
