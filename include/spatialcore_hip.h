@@ -81,7 +81,7 @@ int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
  * 2 = inject a fault into the block-parallel scan (exercises the verification + fallback; tests only). */
 int sc_ctx_set_permgen_mode(sc_ctx *ctx, int mode);
 /* Why the generator is not using its block-parallel form, "" when it is.  The form orders its kernels through words in
- * device memory and needs its streams on different hardware queues (the library asks for GPU_MAX_HW_QUEUES=16 when it is
+ * device memory and needs its streams on different hardware queues (the library asks for GPU_MAX_HW_QUEUES=24 when it is
  * loaded before the HIP runtime initialises -- a host application that initialised HIP first keeps its own setting);
  * the context probes that once (5 rounds of 5-ms waits at worst), falls back to the sequential scan with identical
  * results, and leaves the reason here.  sc_ctx_set_permgen_mode re-arms the probe. */

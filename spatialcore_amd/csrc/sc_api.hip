@@ -15,7 +15,10 @@ static thread_local char g_err[1024] = "";
 // REQUEST, not a requirement: a host application that initialised HIP earlier (or set a smaller value) keeps its
 // setting; the generator probes its streams before its first block-parallel job (permgen_probe_streams), uses the
 // sequential scan when they cannot overlap, and says so through sc_ctx_permgen_note (logged once by the Python layer).
-__attribute__((constructor)) static void sc_request_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// 24 = two contexts' worth: a context creates up to 11 streams, and once a process's streams outnumber the setting the
+// runtime lets them SHARE queues (r03: with 16, a second context in one process found its generator streams on shared
+// queues and fell back; 24 and 32 were measured: same bench step as 16, every test with two live contexts green).
+__attribute__((constructor)) static void sc_request_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 void sc_set_error(const char *fmt, ...)
 {

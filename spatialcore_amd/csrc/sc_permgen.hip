@@ -803,7 +803,7 @@ static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
         const char *q = getenv("GPU_MAX_HW_QUEUES");
         char buf[320];
         snprintf(buf, sizeof(buf), "the HIP streams of this process do not run concurrently (GPU_MAX_HW_QUEUES=%s; the library "
-                 "asks for 16 when it is loaded BEFORE the HIP runtime initialises, or a profiler serialises kernels): the "
+                 "asks for 24 when it is loaded BEFORE the HIP runtime initialises, or a profiler serialises kernels): the "
                  "permutation generator uses its sequential scan (same results, about half the speed)", q ? q : "unset");
         c->pg_note = buf;
     }
