@@ -54,6 +54,14 @@ def test_no_cpu_fallback_without_gpu():
         morans_i(make_adata(coords, X), n_permutations=3)
 
 
+def test_release_default_contexts_without_any_context():
+    """Giving the cached per-device contexts back is a no-op when none was created (and needs no GPU)."""
+    from spatialcore_amd import _lib
+
+    _lib.release_default_contexts()
+    assert _lib._default_ctx == {}
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "spatialcore_amd")):
