@@ -1263,6 +1263,7 @@ static int moran_prepare_early(sc_ctx *c)
     const int blocks = need_s0 ? sc_graph_weight_sum_blocks(c) : 0;
     const size_t bytes = sizeof(double) * ((size_t)blocks + (size_t)(T * SC_TILE)) + sizeof(uint32_t) * 2 * (size_t)Gpad;
     if (bytes > c->prep_host_cap) {
+        SC_HIP(hipStreamSynchronize(c->stream));   // (copies of an earlier, abandoned first half may still be writing the old buffer)
         if (c->prep_host) (void)hipHostFree(c->prep_host);
         c->prep_host = nullptr; c->prep_host_cap = 0;
         SC_HIP(hipHostMalloc(&c->prep_host, bytes, hipHostMallocDefault));
@@ -1453,6 +1454,9 @@ static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int 
     if (!private_lag && (last_task == 0 || last_task >= (BITS == 64 ? 6 * SCORE_WAVES : wg_min))) {
         const int64_t tasks = (int64_t)groups * splits * ((cnt + 8 * SCORE_WAVES - 1) / (8 * SCORE_WAVES));
         if (wgs > tasks) wgs = (int)tasks;
+        // (r03 measured the grid rounded to whole rounds of tasks -- 1956 tasks are 13 rounds on 160 workgroups, 12 on 163,
+        // and 151 suffice for 13: the launches were 3 % shorter with 163, the generator 4 % slower with 3 compute units
+        // fewer, the step the same within its noise either way, and with 151 as well.  Not kept.)
         hipLaunchKernelGGL((k_moran_score_wg<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
                            c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
                            c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
@@ -2569,26 +2573,27 @@ __global__ __launch_bounds__(256) void k_untile(const T *__restrict__ tiles, T *
 
 // Is every loaded value an integer in [0, LM_CODES)?  (one pass over the tiles + one synchronisation; SC_LM_FLOAT_ROWS
 // set: development switch, the float-row form for A/B runs and tests)
-static bool lm_codes_ok(sc_ctx *c)
+static int lm_codes_ok(sc_ctx *c, bool *ok)
 {
-    if (getenv("SC_LM_FLOAT_ROWS") || c->e_n >= ((int64_t)1 << 24)) return false;
+    *ok = false;
+    if (getenv("SC_LM_FLOAT_ROWS") || c->e_n >= ((int64_t)1 << 24)) return SC_OK;   // (16.7M cells: 2 GB of code rows per permutation and group)
     const int64_t n = c->e_n, T = c->e_tiles, G = c->e_genes;
     const int64_t Gpad = align_up64(T, 8) * SC_TILE;
-    if (c->g_flags.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem) != SC_OK || c->g_xmax.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem) != SC_OK)
-        return false;
-    if (hipMemsetAsync(c->g_flags.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream) != hipSuccess ||
-        hipMemsetAsync(c->g_xmax.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream) != hipSuccess)
-        return false;
+    SC_TRY(c->g_flags.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem));
+    SC_TRY(c->g_xmax.ensure(sizeof(uint32_t) * (size_t)Gpad, &c->mem));
+    SC_HIP(hipMemsetAsync(c->g_flags.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream));
+    SC_HIP(hipMemsetAsync(c->g_xmax.p, 0, sizeof(uint32_t) * (size_t)Gpad, c->stream));
     hipLaunchKernelGGL(k_gene_stats, dim3((unsigned)ceil_div64(n, RED_ROWS_PER_BLOCK), (unsigned)T), dim3(256), 0, c->stream,
                        c->X.as<double>(), n, c->g_flags.as<uint32_t>(), c->g_xmax.as<uint32_t>());
+    SC_HIP(hipGetLastError());
     std::vector<uint32_t> flags((size_t)Gpad), xmax((size_t)Gpad);
-    if (hipMemcpyAsync(flags.data(), c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipMemcpyAsync(xmax.data(), c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
-        return false;
+    SC_HIP(hipMemcpyAsync(flags.data(), c->g_flags.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(xmax.data(), c->g_xmax.p, sizeof(uint32_t) * (size_t)Gpad, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
     for (int64_t g = 0; g < G; ++g)
-        if ((flags[(size_t)g] & 1u) || xmax[(size_t)g] >= LM_CODES) return false;
-    return true;
+        if ((flags[(size_t)g] & 1u) || xmax[(size_t)g] >= LM_CODES) return SC_OK;
+    *ok = true;
+    return SC_OK;
 }
 
 // One local Moran job: the operands of the per-cell permutation counts (sc_local_moran, sc_local_moran_seeded)
@@ -2675,7 +2680,9 @@ static int lm_prepare(sc_ctx *c, int64_t n_perm, LmJob &j)
     if (n_perm <= 0) return SC_OK;
     if (c->lm_direct) { j.mode = 0; return SC_OK; }   // r01 form (development A/B, sc_ctx_set_local_moran_direct)
     SC_TRY(sc_graph_ensure_order(c));
-    if (lm_codes_ok(c)) {
+    bool codes = false;
+    SC_TRY(lm_codes_ok(c, &codes));
+    if (codes) {
         // count data: the permuted matrix travels as uint8 code rows, z is looked up where it is used (k_lm_count_u8)
         j.mode = 1;
         j.groups = (int)ceil_div64(T, 8);
