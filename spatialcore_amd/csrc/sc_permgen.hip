@@ -1250,19 +1250,41 @@ __global__ __launch_bounds__(64) void k_apply_swaps(const int32_t *__restrict__ 
 //              order yields its inverse: the INVERSE permutation table comes out of the same kernel, no scatter pass.
 //              Two steps of a round then collide when a later step's target is an earlier step's own slot
 //              (j_l == i_m, again index arithmetic) or two steps share a target.
+// r03: (i) the swap partners j of the coming rounds are PREFETCHED into an LDS ring (they do not depend on anything the
+// rounds do; only WHICH steps a round holds does, by up to SW_T), so a round's memory latency is one dependent access
+// (the values at the partners' slots) instead of two; (ii) in the ascending mode a step's own slot has never been touched
+// when its turn comes (every earlier step i' < i writes slots <= i'), so its value is i itself: no load, and no identity
+// fill of the row beyond slot 0.  -DSW_NO_PREFETCH: the r02 form (A/B builds).
+#define SW_RING 2048   // partners of steps [done, done + <= 1536) live here
+
 template <bool ASC>
 __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
                                                          int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
 {
     __shared__ uint32_t hkey[SW_HASH], hmin[SW_HASH];
     __shared__ uint32_t first_conf[2];
+#ifndef SW_NO_PREFETCH
+    __shared__ int32_t jring[SW_RING];
+#endif
     const int64_t p = p0 + blockIdx.x;
     if (p >= n_perm) return;
     const uint32_t l = threadIdx.x;
     const uint32_t M = n - 1;
     int32_t *A = perm + p * pstride;
     const int32_t *Jp = J + p * (int64_t)M;
+#ifndef SW_NO_PREFETCH
+    // step k = 0 .. M - 1 of the processing order: i = 1 + k (ascending) or n - 1 - k; its partner is Jp[M - i]
+    auto step_i = [&](int64_t k) -> int64_t { return ASC ? 1 + k : (int64_t)n - 1 - k; };
+    if (!ASC) { for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x; }
+    else if (l == 0) A[0] = 0;
+    for (int r = 0; r < 2; ++r) {   // partners of the first 2 SW_T steps
+        const int64_t k = (int64_t)r * SW_T + l;
+        jring[k & (SW_RING - 1)] = k < (int64_t)M ? Jp[(int64_t)M - step_i(k)] : -1;
+    }
+    int64_t filled = 2 * SW_T;      // partners of steps [done, filled) are in the ring
+#else
     for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x;
+#endif
     if (l < 2) first_conf[l] = SW_T;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1272,12 +1294,26 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
     while (ASC ? i_cur <= (int64_t)n - 1 : i_cur >= 1) {
         const int64_t i = ASC ? i_cur + l : i_cur - l;
         const bool valid = ASC ? i <= (int64_t)n - 1 : i >= 1;
+#ifndef SW_NO_PREFETCH
+        const int64_t done = ASC ? i_cur - 1 : (int64_t)n - 1 - i_cur;   // steps applied so far
+        int32_t j = valid ? jring[(done + l) & (SW_RING - 1)] : -1;
+        // the ring's next SW_T partners are on their way while this round works (stored at its end)
+        const bool top_up = filled - done <= 2 * SW_T;
+        const int64_t kf = filled + l;
+        int32_t j_next = -1;
+        if (top_up && kf < (int64_t)M) j_next = Jp[(int64_t)M - step_i(kf)];
+#else
         int32_t j = valid ? Jp[(int64_t)M - i] : -1;
+#endif
         if (valid && (uint32_t)j > (uint32_t)i) j = (int32_t)i;  // never index outside [0, i], whatever J holds
         int32_t a_i = 0, a_j = 0;
         if (valid) {  // L1 is bypassed: the values the previous round stored are in L2 (vmcnt wait + barrier)
+#ifndef SW_NO_PREFETCH
+            a_i = ASC ? (int32_t)i : __hip_atomic_load(&A[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             a_i = __hip_atomic_load(&A[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a_j = __hip_atomic_load(&A[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            a_j = (ASC && j == (int32_t)i) ? a_i : __hip_atomic_load(&A[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int k = 0; k < SW_HASH / SW_T; ++k) { hkey[l + SW_T * k] = 0xffffffffu; hmin[l + SW_T * k] = 0xffffffffu; }
@@ -1312,6 +1348,9 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
             A[i] = a_j;
             if (j != (int32_t)i) A[j] = a_i;
         }
+#ifndef SW_NO_PREFETCH
+        if (top_up) { jring[kf & (SW_RING - 1)] = j_next; filled += SW_T; }   // (uniform; slots of steps already applied)
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         i_cur += ASC ? (int64_t)count : -(int64_t)count;
