@@ -53,6 +53,12 @@ def test_knn_bit_exact(ctx, oracle, n, k):
     np.testing.assert_array_equal(idx, want)
     d = xy[:, None, :] - xy[want]
     np.testing.assert_array_equal(rd, d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+    # the same search without waiting, the lists fetched afterwards on the side stream (what morans_i does beside its upload)
+    assert ctx.knn(xy, k, fetch=False) is None
+    ctx.graph_from_knn(1.0 / k)
+    idx2, rd2 = ctx.knn_fetch()
+    np.testing.assert_array_equal(idx2, want)
+    np.testing.assert_array_equal(rd2, rd)
 
 
 def test_knn_include_self_and_clustered(ctx, oracle):
