@@ -100,7 +100,10 @@ int sc_ctx_permgen_stats(sc_ctx *ctx, int64_t *jobs_parallel, int64_t *jobs_sequ
  * squared distance = fl(fl(dx*dx) + fl(dy*dy)) in fp64 (no FMA contraction), as the tree codes
  * compute it.  Self is excluded BY INDEX unless include_self (then k counts self, AC:398).
  * rdist_out (nullable): [n][k] squared distances.  The result also stays on the device and can be
- * turned into the active graph with sc_graph_from_knn. */
+ * turned into the active graph with sc_graph_from_knn.
+ * LIFETIME: with both output pointers null the call returns WITHOUT waiting for the device -- the upload of `xy` is
+ * then merely enqueued, so `xy` must stay valid and unmodified until the next call on this context that waits
+ * (sc_knn_fetch, sc_ctx_sync, any call that returns results); kernel errors of the search surface there as well. */
 int sc_knn_2d(sc_ctx *ctx, const double *xy, int64_t n, int k, int include_self,
               int32_t *idx_out, double *rdist_out);
 /* The neighbour lists of the last sc_knn_2d that was called WITHOUT output arrays (it then returns without waiting),

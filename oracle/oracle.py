@@ -384,14 +384,18 @@ def morans_i_sims_gather(g: csr_matrix, vals: np.ndarray, perms: np.ndarray) -> 
 
 def lattice_genes(g: csr_matrix, vals: np.ndarray) -> np.ndarray:
     """Genes whose permutation statistic lives on an integer lattice: every value an integer count in [0, 65535] and
-    every stored weight of the graph equal (a kNN graph after l1 row normalisation: 1/k).  With S = A x (A = 0/1
-    adjacency) sum_i z[i] lag[perm[i]] = w (T_perm - mean * sum S) in exact arithmetic, T_perm = sum_i x[i] S[perm[i]]
-    an integer: a permutation can TIE the observed value exactly.  The reference's float loop (scanpy's numba kernel
+    every stored weight of the graph equal AND every row of the same degree d (a kNN graph after l1 row normalisation:
+    w = 1/k, d = k).  With S = A x (A = 0/1 adjacency) sum_i z[i] lag[perm[i]] = w (T_perm - mean * sum S) in exact
+    arithmetic, T_perm = sum_i x[i] S[perm[i]] an integer: a permutation can TIE the observed value exactly.  (With
+    unequal degrees the term -w mean sum_i (x[i] - mean) deg[perm[i]] is left over and depends on the permutation: such
+    graphs -- a binary adjacency of a radius graph, say -- take the ordinary arithmetic.)  The reference's float loop (scanpy's numba kernel
     behind AC:576-583) decides such ties by the rounding noise of its summation order -- nothing reproducible; the
     exact-arithmetic outcome (a tie counts as >=, as `sims >= I` reads) is what this oracle pins."""
     vals = np.asarray(vals)
-    data = csr_matrix(g).data
-    uniform = data.size > 0 and bool((data == data[0]).all()) and data[0] > 0
+    g = csr_matrix(g)
+    data = g.data
+    deg = np.diff(g.indptr)
+    uniform = data.size > 0 and bool((data == data[0]).all()) and data[0] > 0 and int(deg.min()) == int(deg.max())
     ok = np.zeros(vals.shape[0], dtype=bool)
     if uniform:
         with np.errstate(invalid="ignore"):

@@ -104,6 +104,7 @@ struct sc_ctx {
     DBuf g_indptr, g_indices, g_data;
     double g_uniform_w = 0.0;   // > 0: every stored weight equals this value (kNN graphs: 1 / k); 0: weights differ
     int64_t g_deg_max = 0;      // longest row
+    bool g_regular = false;     // every row has g_deg_max entries
     bool gt_valid = false;
     DBuf gt_indptr, gt_indices, gt_data, gt_cursor;
     // the full moments (transpose + reverse-edge search: 6 ms at 1M x 15) may be in flight on a side stream, begun by the

@@ -474,6 +474,7 @@ extern "C" int sc_radius_count_2d(sc_ctx *c, const double *xy, int64_t n, double
     SC_REQUIRE(radius > 0 && isfinite(radius), SC_ERR_INVALID, "radius must be > 0, got %g", radius);
     SC_HIP(hipSetDevice(c->device));
     c->radius = -1.0;
+    sc_graph_moments_drain(c);   // (a moments job on the side stream uses gt_cursor and reads the graph's arrays)
     // bins no smaller than the radius: a 3x3 window always covers the closed ball
     SC_TRY(build_bins(c, xy, n, 4.0, radius));
     int rings = (int)ceil(radius / c->gh * (1.0 + 1e-9));
@@ -513,6 +514,7 @@ extern "C" int sc_radius_fill_2d(sc_ctx *c, int64_t nnz, int32_t *indices_out)
     SC_REQUIRE(total == nnz, SC_ERR_INVALID, "sc_radius_fill_2d: nnz=%lld but the count pass found %lld",
                (long long)nnz, total);
     SC_REQUIRE(nnz == 0 || indices_out, SC_ERR_INVALID, "sc_radius_fill_2d: null output");
+    sc_graph_moments_drain(c);   // (... and this pass overwrites, maybe reallocates, g_indices)
     SC_TRY(c->g_indices.ensure(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1), &c->mem));
     int rings = (int)ceil(c->radius / c->gh * (1.0 + 1e-9));
     if (rings < 1) rings = 1;
@@ -673,10 +675,12 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     SC_REQUIRE(n >= 1 && n <= 0x7fffffffLL && nnz >= 0, SC_ERR_INVALID, "sc_graph_set_csr: bad shape");
     SC_REQUIRE(nnz == 0 || (indices && data), SC_ERR_INVALID, "sc_graph_set_csr: null indices/data");
     SC_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, SC_ERR_INVALID, "sc_graph_set_csr: indptr does not span nnz");
-    int64_t deg_max = 0;
+    int64_t deg_max = 0, deg_min = INT64_MAX;
     for (int64_t i = 0; i < n; ++i) {
         SC_REQUIRE(indptr[i + 1] >= indptr[i], SC_ERR_INVALID, "sc_graph_set_csr: indptr not monotone");
-        if (indptr[i + 1] - indptr[i] > deg_max) deg_max = indptr[i + 1] - indptr[i];
+        const int64_t deg = indptr[i + 1] - indptr[i];
+        if (deg > deg_max) deg_max = deg;
+        if (deg < deg_min) deg_min = deg;
     }
     // all weights equal (a kNN graph after row normalisation: 1 / k)?  Integer-count genes then sit on an integer
     // lattice and their permutation counts are decided exactly (sc_moran.hip, "lattice genes")
@@ -715,6 +719,7 @@ extern "C" int sc_graph_set_csr(sc_ctx *c, const int64_t *indptr, const int32_t 
     c->g_nnz = nnz;
     c->g_uniform_w = uniform_w;
     c->g_deg_max = deg_max;
+    c->g_regular = deg_min == deg_max;   // (the lattice form of the Moran statistic needs equal weights AND equal degrees)
     return SC_OK;
 }
 
@@ -761,6 +766,7 @@ extern "C" int sc_graph_from_knn(sc_ctx *c, double weight)
     c->g_nnz = nnz;
     c->g_uniform_w = (weight > 0.0 && weight < 1e300) ? weight : 0.0;
     c->g_deg_max = c->knn_k;
+    c->g_regular = true;
     return SC_OK;
 }
 

@@ -1303,7 +1303,9 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     std::vector<double> lat((size_t)Gpad, 0.0);
     int bits = c->source_bits_min;
     bool lat_any = false, lat_all = true;
-    const bool lattice_graph = allow_lattice && c->g_uniform_w > 0.0;
+    // equal weights AND equal degrees: sum_i z_i lag[pi(i)] = w (T - mean sum S) drops the term -w mean sum_i z_i deg[pi(i)],
+    // which vanishes only when deg is constant (r03 advisor finding: a binary adjacency with unequal rows took this path)
+    const bool lattice_graph = allow_lattice && c->g_uniform_w > 0.0 && c->g_regular;
     for (int64_t g = 0; g < G; ++g) {
         const int cls = !(flags[(size_t)g] & 1u) ? 8 : !(flags[(size_t)g] & 2u) ? 16 : !(flags[(size_t)g] & 4u) ? 32 : 64;
         if (cls > bits) bits = cls;
@@ -1688,6 +1690,12 @@ static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_pe
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "permutation pipeline: n_perm must be >= 1");
     SC_REQUIRE(table == 0 || permgen_can_swap_inverse(n) || table == 2, SC_ERR_STATE, "inverse-only tables need a longer permutation");
     SC_TRY(sc_perm_alloc(c, n, n_perm));
+    // the resident table is being overwritten from here on: nothing may take it for valid until the job has been consumed
+    // (sc_moran / sc_local_moran / sc_lee_shared with a resident table then fail with "holds 0 rows" instead of reading
+    // rows the generator's streams are still writing)
+    c->p_count = 0;
+    c->inv_rows_valid = 0;
+    c->perm_forward_valid = false;
     if (!c->stream2) {  // (SC_STREAM_PRIORITY=1: the r01 prioritised chain stream, for experiments; no gain measured in r02)
         int prio_lo = 0, prio_hi = 0;
         if (!getenv("SC_STREAM_PRIORITY") || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||

@@ -58,18 +58,40 @@ def _launcher_identity() -> str:
     return f"{os.getuid()}_{ppid}_{started}_{os.environ.get('MASTER_PORT', '0')}"
 
 
+def _private_rendezvous_dir() -> str:
+    """A directory only this user can write to (0700, owned by us, not a symlink): the default home of the rendezvous
+    files, so that another local user can neither plant an id nor pre-create the temp name (r03 advisor finding: the
+    name and the nonce are computable from public facts)."""
+    import stat
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), f"sc_rdv_{os.getuid()}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {path} is not a private directory of this user; "
+                              "set SC_RENDEZVOUS_DIR to one")
+    return path
+
+
 def rendezvous_file(seq: int = 0) -> str:
-    """Where rank 0 leaves the RCCL id for the other ranks (``SC_RENDEZVOUS_FILE`` overrides)."""
+    """Where rank 0 leaves the RCCL id for the other ranks (``SC_RENDEZVOUS_FILE`` / ``SC_RENDEZVOUS_DIR`` override;
+    the default is a 0700 per-user directory under the system's temp directory)."""
     base = os.environ.get("SC_RENDEZVOUS_FILE")
     if not base:
-        base = os.path.join(os.environ.get("SC_RENDEZVOUS_DIR", "/tmp"), f"sc_rccl_{_launcher_identity()}")
+        d = os.environ.get("SC_RENDEZVOUS_DIR") or _private_rendezvous_dir()
+        base = os.path.join(d, f"sc_rccl_{_launcher_identity()}")
     return f"{base}.{seq}"
 
 
 def _launch_nonce() -> bytes:
     """16 bytes that every rank of ONE launch computes alike and no other launch does (launcher pid + start time +
-    port + uid): rank 0 prefixes the RCCL id with it, the others ignore files that carry another one -- a file left
-    behind by a crashed launch, or put at a predictable path by someone else, is never taken for this launch's id."""
+    port + uid): rank 0 prefixes the RCCL id with it, the others ignore files that carry another one.  It guards
+    against STALE files (a crashed launch that left its id behind) only -- every input is public, so it is no secret;
+    protection against other local users comes from where the file lives (``_private_rendezvous_dir``)."""
     import hashlib
 
     return hashlib.sha256(("sc-rdv-v1:" + _launcher_identity()).encode()).digest()[:16]
@@ -93,7 +115,12 @@ def _await_id(path: str, nonce: bytes, id_bytes: int, timeout_s: float) -> bytes
 
 def _publish(path: str, payload: bytes) -> None:
     tmp = f"{path}.tmp{os.getpid()}"
-    with open(tmp, "wb") as f:
+    try:
+        os.unlink(tmp)           # (a leftover of a crashed launch with our pid)
+    except FileNotFoundError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)   # never through a planted link
+    with os.fdopen(fd, "wb") as f:
         f.write(payload)
     os.replace(tmp, path)        # atomic: a reader sees nothing or everything
 

@@ -50,8 +50,11 @@ def oracle():
     return orc
 
 
-def synth(n, n_genes, seed, dtype=np.float64, sparse_x=True):
-    """Tie-free coordinates + half smooth / half Poisson genes (same recipe as oracle/make_golden.py)."""
+def synth(n, n_genes, seed, dtype=np.float64, sparse_x=True, normalize=False):
+    """Tie-free coordinates + half smooth / half Poisson genes (same recipe as oracle/make_golden.py).
+    normalize=True: the usual input of Moran's I instead of raw counts -- per-cell size factors + log1p
+    (scanpy's normalize_total + log1p), float32: no value is an integer, no gene sits on the integer lattice, so the
+    ordinary (centred, rounded) arithmetic of the float32-source kernels is what runs."""
     from scipy import sparse
 
     rng = np.random.default_rng(seed)
@@ -68,6 +71,10 @@ def synth(n, n_genes, seed, dtype=np.float64, sparse_x=True):
             X[:, g] = rng.poisson(lam * field)
         else:
             X[:, g] = rng.poisson(lam, n)
+    if normalize:
+        depth = X.sum(axis=1, keepdims=True) + rng.uniform(0.5, 1.5, (n, 1))   # (no empty cell, no two equal depths)
+        X = np.log1p(X / depth * np.median(depth)).astype(np.float32)
+        dtype = np.float32
     X = X.astype(dtype)
     return coords, (sparse.csr_matrix(X) if sparse_x else X)
 

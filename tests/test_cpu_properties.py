@@ -148,3 +148,21 @@ def test_lattice_count_is_the_exact_arithmetic_count(seed, n, k):
     # a graph with unequal weights has no lattice genes
     g2 = g.copy(); g2.data[0] *= 0.5
     assert not orc.lattice_genes(g2, vals).any()
+    # ... nor has one with equal weights but unequal degrees (r03 advisor finding): the identity behind the lattice form
+    # loses the term -w mean sum_i z_i deg[perm_i], which depends on the permutation -- shown here in exact arithmetic
+    keep = np.ones(n * k, dtype=bool); keep[: k - 1] = False                 # row 0 keeps one neighbour
+    indptr3 = np.concatenate([[0], np.cumsum(np.where(np.arange(n) == 0, 1, k))])
+    g3 = csr_matrix((np.ones(int(keep.sum())), idx.reshape(-1)[keep], indptr3), shape=(n, n))
+    assert not orc.lattice_genes(g3, vals).any()
+    x = [Fraction(int(v)) for v in vals[1]]
+    mean = sum(x) / n
+    z = [v - mean for v in x]
+    rows = [g3.indices[g3.indptr[i]:g3.indptr[i + 1]] for i in range(n)]
+    S = [sum(x[j] for j in rows[i]) for i in range(n)]
+    lag = [sum(z[j] for j in rows[i]) for i in range(n)]
+    diffs = set()
+    for p in range(6):
+        exact = sum(z[i] * lag[perms[p][i]] for i in range(n))
+        T = sum(x[i] * S[perms[p][i]] for i in range(n))
+        diffs.add(exact - (T - mean * sum(S)))
+    assert len(diffs) > 1                                                     # not a constant offset: counts would differ

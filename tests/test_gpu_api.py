@@ -55,6 +55,27 @@ def test_morans_i_table_matches_oracle(oracle):
     np.testing.assert_allclose(ad.uns["m0"]["p_value"].values, t0["p_value"], rtol=1e-6, atol=1e-300)
 
 
+def test_morans_i_table_matches_oracle_on_log_normalised_values(oracle):
+    """The usual input of Moran's I -- size-factor normalised, log1p'ed float32 values: no integer, no lattice gene --
+    through the public function: the centred float32-source kernel.  I and z at 1e-9; p-values equal to the oracle's
+    except where a permutation's statistic is within rounding noise of the observed one (none here, asserted)."""
+    from spatialcore_amd.spatial import morans_i
+
+    coords, X = synth(10000, 50, 1, normalize=True)             # BASELINE configs[0], log-normalised
+    ad = make_adata(coords, X)
+    cols = [3, 0, 17, 42, 8, 49, 21]
+    genes = [f"g{i}" for i in cols]
+    morans_i(ad, genes=genes, n_neighbors=6, n_permutations=199, seed=0)
+    df = ad.uns["morans_i"]
+    tab = oracle.morans_i_reference_table(coords, X, cols, 6, 199, seed=0)
+    assert not tab["lattice"].any()
+    np.testing.assert_allclose(df["I"].values, tab["I"], rtol=1e-9)
+    np.testing.assert_allclose(df["z_score"].values, tab["z_score"], rtol=1e-9)
+    near = (np.abs(tab["sims"] - tab["I"]) <= 1e-11 * np.abs(tab["I"])).sum(axis=0)
+    assert (near == 0).all()                                    # no rounding-level near-tie in this data: p must be EQUAL
+    np.testing.assert_array_equal(df["p_value"].values, tab["p_value"])
+
+
 def test_morans_i_gene_batches_share_the_permutation_table():
     """Genes scored in device batches (a matrix too wide for HBM) see the same permutations: the table of the first
     batch stays resident.  Batched == unbatched, bit for bit, dense and sparse, 130 permutations (two chunks)."""
@@ -409,6 +430,12 @@ def test_counter_permutations_on_the_device_and_lee_shared_philox(oracle):
     for n, P, p0 in [(1, 3, 0), (2, 5, 1), (1000, 9, 4), (70001, 6, 2**33 + 1)]:
         got = ctx.generate_permutations_counter(123, n, P, p_first=p0, fetch=True)
         np.testing.assert_array_equal(got, _lib.perm_counter_host(123, n, P, p_first=p0))
+    # ... and the ORACLE's restatement of the definition directly (numpy Philox4x32-10 pinned by Random123's known answers,
+    # python-integer Lemire): the workgroup swap form (n >= 65536) and the wavefront form, rows far apart in p
+    for n, p0 in [(70001, 0), (70001, 2**33 + 5), (3001, 7)]:
+        got = ctx.generate_permutations_counter(123, n, 2, p_first=p0, fetch=True)
+        for r in range(2):
+            np.testing.assert_array_equal(got[r], oracle.counter_permutation(123, n, p0 + r), err_msg=f"n={n} p={p0 + r}")
     n, G, P = 4000, 6, 19
     coords, X = synth(n, G, 9, dtype=np.float64, sparse_x=False)
     ad = make_adata(coords, X)

@@ -216,15 +216,18 @@ def test_graph_rejects_bad_input(ctx):
         ctx.set_graph_csr([0, 2, 2], [1, 0], [1.0, 1.0], 2)       # unsorted row
 
 
-@pytest.mark.parametrize("n,G,k,P,dtype,sparse_x", [
-    (3000, 5, 6, 19, np.float64, True),
-    (10000, 50, 6, 199, np.float32, True),      # BASELINE configs[0]
-    (2500, 33, 15, 40, np.float32, False),
-    (777, 17, 4, 33, np.float64, False),        # ragged: n, G, P not multiples of anything
+@pytest.mark.parametrize("n,G,k,P,dtype,sparse_x,normalize", [
+    (3000, 5, 6, 19, np.float64, True, False),
+    (10000, 50, 6, 199, np.float32, True, False),      # BASELINE configs[0]
+    (2500, 33, 15, 40, np.float32, False, False),
+    (777, 17, 4, 33, np.float64, False, False),        # ragged: n, G, P not multiples of anything
+    (10000, 50, 6, 199, np.float32, True, True),       # configs[0] on log-normalised values: no lattice gene,
+    (777, 37, 4, 33, np.float32, False, True),         # ... the centred float32-source kernel over whole permutation sets
 ])
-def test_moran_vs_oracle(ctx, oracle, n, G, k, P, dtype, sparse_x):
-    coords, X = synth(n, G, 17, dtype=dtype, sparse_x=sparse_x)
+def test_moran_vs_oracle(ctx, oracle, n, G, k, P, dtype, sparse_x, normalize):
+    coords, X = synth(n, G, 17, dtype=dtype, sparse_x=sparse_x, normalize=normalize)
     tab = oracle.morans_i_reference_table(coords, X, list(range(G)), k, P, seed=0)
+    assert tab["lattice"].any() != normalize
     ctx.knn(coords, k, fetch=False)
     ctx.graph_from_knn(1.0 / k)
     ctx.set_expression(X, np.arange(G))
@@ -235,6 +238,7 @@ def test_moran_vs_oracle(ctx, oracle, n, G, k, P, dtype, sparse_x):
     np.testing.assert_array_equal(perms, tab["perms"])                 # bit-exact numpy stream
     assert (words == oracle.perm_table(0, n, P)[1]).all()
     out = ctx.moran(P)
+    assert ctx.moran_source_bits() == (32 if normalize else 8)
     np.testing.assert_allclose(out["I"], tab["I"], rtol=1e-9, atol=1e-14)
     np.testing.assert_allclose(out["sims"], tab["sims"], rtol=1e-9, atol=1e-13)
     assert_counts_match(out["count_ge"], tab)
@@ -313,23 +317,25 @@ def test_moran_seeded_in_two_halves_equals_one_call(ctx, oracle, n, P):
         ctx.moran_seeded_finish(w3)
 
 
-@pytest.mark.parametrize("n,G,seed", [(5000, 70, 0), (4096, 33, 9)])
-def test_moran_seeded_bench_schedule_p1000_vs_oracle(ctx, oracle, n, G, seed):
+@pytest.mark.parametrize("n,G,seed,normalize", [(5000, 70, 0, False), (4096, 33, 9, False), (5000, 70, 0, True)])
+def test_moran_seeded_bench_schedule_p1000_vs_oracle(ctx, oracle, n, G, seed, normalize):
     """The exact schedule bench.py runs: P = 1000 > 3 chunks switches sc_moran_seeded to the short-first /
     128 x 7 / short-last chunk bounds, and G = 70 / 33 leaves an odd 16-gene tile count for the 32-gene kernel.
     Every permutation's statistic, the counts and the final generator state against the oracle."""
     from spatialcore_amd._lib import rng_state_words
 
     P, k = 1000, 15
-    coords, X = synth(n, G, 101 + seed, dtype=np.float32)
+    coords, X = synth(n, G, 101 + seed, dtype=np.float32, normalize=normalize)
     tab = oracle.morans_i_reference_table(coords, X, list(range(G)), k, P, seed=seed)
+    assert tab["lattice"].all() != normalize and tab["lattice"].any() != normalize
     ctx.knn(coords, k, fetch=False)
     ctx.graph_from_knn(1.0 / k)
     ctx.set_expression(X, np.arange(G))
     w = rng_state_words(np.random.default_rng(seed))
     before = ctx.permgen_stats()
     out = ctx.moran_seeded(w, P)
-    assert ctx.moran_source_bits() == 8                                 # small counts: uint8 source, 128 genes per row
+    assert ctx.moran_source_bits() == (32 if normalize else 8)          # small counts: uint8 source, 128 genes per row;
+                                                                        # log-normalised values: float32 source, centred
     assert ctx.permgen_stats()[2] == before[2]                         # no silent verification fallback
     np.testing.assert_array_equal(w, oracle.perm_table(seed, n, P)[1])  # generator state after P permutations
     np.testing.assert_allclose(out["I"], tab["I"], rtol=1e-9, atol=1e-14)
@@ -529,6 +535,52 @@ def test_moran_gene_results_do_not_depend_on_coloaded_genes(ctx, oracle, graph):
     want = np.stack([scale * (z * lag[:, idx[p]]).sum(axis=1) for p in range(5)])
     np.testing.assert_allclose(free["sims"], want, rtol=1e-9, atol=1e-13)
     np.testing.assert_array_equal(free["count_ge"], (free["sims"] >= free["I"]).sum(axis=0))
+
+
+def test_moran_uniform_weights_unequal_degrees_take_the_ordinary_arithmetic(ctx, oracle):
+    """r03 advisor finding: the integer-lattice form sum_i z_i lag[pi(i)] = w (T - mean sum S) needs equal weights AND
+    equal row degrees (otherwise -w mean sum_i z_i deg[pi(i)] is left over and depends on the permutation).  A binary
+    adjacency of a radius graph (every stored weight 1.0, degrees 2 .. 30, some empty rows) with integer counts must
+    therefore take the ordinary arithmetic: I, every permutation's statistic and the counts against the oracle's CSR sweep /
+    gather form on that very graph; a regular graph with the same weights still is a lattice graph."""
+    n, G, P = 5000, 9, 60
+    coords, X = synth(n, G, 44, dtype=np.float64, sparse_x=False)
+    indptr, indices = oracle.radius_neighbors(coords, 16.0)
+    deg = np.diff(indptr)
+    assert deg.min() < deg.max()
+    g = csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))      # NOT row-normalised: all weights equal
+    vals = oracle.dense_genes(X)
+    assert not oracle.lattice_genes(g, vals).any()
+    perms, _ = oracle.perm_table(3, n, P)
+    want_I = oracle.morans_i_scores(g, vals)
+    want_sims = oracle.morans_i_sims_gather(g, vals, perms)
+    want_lit = np.stack([oracle.morans_i_scores(g, vals, perms[p]) for p in range(3)])      # the literal row-permuted sweep
+    np.testing.assert_allclose(want_sims[:3], want_lit, rtol=1e-10, atol=1e-14)
+    ctx.set_graph_csr(indptr, indices, np.ones(indices.size), n)
+    ctx.set_expression(X, np.arange(G))
+    ctx.set_permutations(perms)
+    out = ctx.moran(P)
+    assert ctx.moran_source_bits() == 16                  # integer counts, but no lattice gene: the centred uint16 kernel
+    np.testing.assert_allclose(out["I"], want_I, rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(out["sims"], want_sims, rtol=1e-9, atol=1e-13)
+    count, lat = oracle.morans_count_ge(g, vals, perms, want_sims, want_I)
+    assert not lat.any()
+    assert_counts_match(out["count_ge"], {"lattice": lat, "count_ge": count, "sims": want_sims, "I": want_I})
+    # the same weights on a regular graph (kNN, every row k entries of weight 1.0): lattice genes, exact counts
+    k = 7
+    nbr = np.sort(oracle.knn_tree(coords, k), axis=1)
+    gk = csr_matrix((np.ones(n * k), nbr.reshape(-1), np.arange(0, n * k + 1, k)), shape=(n, n))
+    assert oracle.lattice_genes(gk, vals).all()
+    ctx.set_graph_csr(gk.indptr, gk.indices, gk.data, n)
+    ctx.set_expression(X, np.arange(G))
+    ctx.set_permutations(perms)
+    outk = ctx.moran(P)
+    assert ctx.moran_source_bits() == 8
+    simsk = oracle.morans_i_sims_gather(gk, vals, perms)
+    Ik = oracle.morans_i_scores(gk, vals)
+    np.testing.assert_allclose(outk["sims"], simsk, rtol=1e-9, atol=1e-13)
+    countk, latk = oracle.morans_count_ge(gk, vals, perms, simsk, Ik)
+    np.testing.assert_array_equal(outk["count_ge"], countk)
 
 
 def test_moran_gene_subset_and_uploaded_perms(ctx, oracle):
