@@ -24,7 +24,12 @@ if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE
         if cnt:
             print(f"computed blocks with {nm}: {cnt / jobs:.2f} per permutation, {clk / cnt:.0f} clocks and {rounds / cnt:.1f} rounds each, {clk / jobs:.0f} clocks per permutation")
     easy, hard = 64 * (int(st[6]) & 0xffffffff), 64 * (int(st[6]) >> 32)
-    print(f"chain clocks of the last job: lookup phases {easy / 1e6:.1f}M = {easy / max(int(st[4]), 1):.0f} per block, {easy / max(int(st[7]), 1):.0f} per pass "
-          f"({int(st[7])} passes); computed blocks {hard / 1e6:.1f}M = {hard / max(int(st[5]), 1):.0f} each")
+    print(f"chain clocks of the last job: lookup phases (segments + slow paths) {easy / 1e6:.1f}M = {easy / max(int(st[4]), 1):.0f} per block resolved by lookup; "
+          f"computed blocks {hard / 1e6:.1f}M = {hard / max(int(st[5]), 1):.0f} each; slow paths {int(st[7])}")
+    print(f"all {jobs} permutations: waiting for a unit's preparation {int(prof[20]) / jobs:.0f} clocks per permutation; slow paths (a segment's window "
+          f"missed) {int(prof[22]) / jobs:.2f} per permutation, {int(prof[21]) / max(int(prof[22]), 1):.0f} clocks each; exposed table loads {int(prof[23]) / jobs:.2f} per permutation")
+    nb = max(int(prof[25]), 1)
+    print(f"fixed point of the computed blocks: first evaluation (guess + 16 draws) {int(prof[24]) / nb:.0f} clocks of thread 0; wavefronts that recompute "
+          f"after round 1 / 2 / 3 / later: {int(prof[26]) / nb:.1f} / {int(prof[27]) / nb:.1f} / {int(prof[28]) / nb:.1f} / {int(prof[29]) / nb:.1f} of 16 per block")
 else:
-    print(f"last job: {int(st[4])} blocks by lookup, of which {int(st[6])} in fast passes ({int(st[7])} passes); {int(st[5])} computed")
+    print(f"last job: {int(st[4])} blocks by lookup in {int(st[6])} segment lookups, {int(st[7])} segments block by block (window missed); {int(st[5])} computed")

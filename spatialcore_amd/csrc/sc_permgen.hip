@@ -272,6 +272,10 @@ __device__ __forceinline__ uint32_t expected_steps(uint32_t rem, float q, uint32
     return (uint32_t)(acc + 0.5f);
 }
 
+#ifdef PHI_PROFILE
+__device__ unsigned long long g_phi_prof[32];   // development: see k_chain, block_fixed_point (read by sc_permgen_profile)
+#endif
+
 struct BlockShared {
     uint32_t wsum[2][SCAN_THREADS / 64];   // per wavefront: accept count | (recomputed something last round) << 31; by round parity
 };
@@ -311,7 +315,13 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
     const uint64_t left = total_steps - S_block;
     const uint32_t limit = left > 0xffffffffULL ? 0xffffffffu : (uint32_t)left;
     // first guess of the entering count: the expected count (any guess converges; a good one saves rounds)
+#ifdef PHI_PROFILE
+    const long long pf_a = clock64();
+#endif
     scan_thread(u, expected_steps(rem_block, (float)(tau * SCAN_D), M), rem_block, M, top_mask, limit, r);
+#ifdef PHI_PROFILE
+    if (rounds_out && tau == 0) { atomicAdd(&g_phi_prof[24], (unsigned long long)(clock64() - pf_a)); atomicAdd(&g_phi_prof[25], 1ull); }
+#endif
     excl = 0; total_cnt = 0;
     uint32_t recomputed = 1u;
     for (int iter = 0;; ++iter) {
@@ -331,6 +341,11 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         }
         const bool stale = !scan_still_valid(r, excl, M, limit);
         recomputed = __any(stale) ? 1u : 0u;
+#ifdef PHI_PROFILE
+        if (rounds_out && lane == 0) {   // wavefronts that recompute, by round (1, 2, 3, later)
+            if (recomputed) atomicAdd(&g_phi_prof[26 + (iter < 3 ? iter : 3)], 1ull);
+        }
+#endif
         if (recomputed) {
             if (stale) scan_thread(u, excl, rem_block, M, top_mask, limit, r);
         }
@@ -496,7 +511,7 @@ struct PhiDesc {
     uint16_t w_neg;        // entry states G - d, 0 <= d <= w_neg, are covered (trajectories behind the base)
     uint16_t n_pos, n_neg; // events per side
     uint32_t prepared;     // 0: the chain computes this block itself
-    uint32_t pad_;
+    uint32_t w;            // the window the block was prepared for (w_pos / w_neg are smaller next to a band edge)
 };
 
 // Expected state after dq more draws from state S (mean-field, closed form per mask band).  Only a guess:
@@ -671,7 +686,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
         if (totP > PHI_MAX_EV || totN > PHI_MAX_EV) easy = false;
     }
     PhiDesc d;
-    d.G = G; d.cnt = total_cnt; d.i_in = i_in; d.pad_ = 0;
+    d.G = G; d.cnt = total_cnt; d.i_in = i_in; d.w = w;
     d.w_pos = (uint16_t)w_pos; d.w_neg = (uint16_t)w_neg; d.n_pos = (uint16_t)totP; d.n_neg = (uint16_t)totN;
     d.prepared = easy ? 1u : 0u;
     if (tau == 0) desc[slot] = d;
@@ -699,25 +714,6 @@ __global__ __launch_bounds__(128) void k_phi_tbuild(uint64_t b0, uint64_t b1, co
     const uint32_t side = threadIdx.x >> 6;
     phi_tbuild(events + (slot * 2 + side) * PHI_MAX_EV, side ? d.n_neg : d.n_pos, side ? d.w_neg : d.w_pos,
                tbits + (slot * 2 + side) * PHI_WORDS);
-}
-
-#ifndef PHI_STAGE
-#define PHI_STAGE 16          // prepared blocks of a run whose tables are staged in LDS
-#endif
-#define PHI_STAGE_WORDS 128   // ... their first 8192 bits per side (entry gaps beyond that read global memory)
-
-// exit gap from a staged table (wave 0 only, all lanes): lane l holds bits [128 l, 128 l + 128)
-__device__ __forceinline__ uint32_t phi_lookup_lds(const ulonglong2 *tl, uint32_t idx)
-{
-    const uint32_t lane = threadIdx.x & 63, base = 128 * lane;
-    uint32_t t = 0;
-    if (idx > base) {
-        const ulonglong2 a = tl[lane];
-        const uint32_t d = idx - base;   // >= 1
-        t = (uint32_t)__popcll(a.x & sc_low_mask64(d < 64u ? d : 64u));
-        if (d > 64u) t += (uint32_t)__popcll(a.y & sc_low_mask64(d - 64u < 64u ? d - 64u : 64u));
-    }
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(t), 63);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,7 +807,6 @@ static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
 }
 
 #ifdef PHI_PROFILE
-__device__ unsigned long long g_phi_prof[32];   // development: see k_chain (read by sc_permgen_profile)
 int sc_permgen_profile(unsigned long long *out32, int reset)
 {
     SC_HIP(hipDeviceSynchronize());
@@ -826,16 +821,218 @@ int sc_permgen_profile(unsigned long long *out32, int reset)
 int sc_permgen_profile(unsigned long long *out32, int) { memset(out32, 0, sizeof(unsigned long long) * 32); return SC_OK; }
 #endif
 
-// Chain the exact states through blocks [b0, b1) (one workgroup): prepared blocks cost one table lookup by
-// wavefront 0, the others the full in-block fixed point.  While a block is computed, the draws of the next
-// block to compute and the tables of the run of prepared blocks before it are already on their way (registers,
-// then LDS).  Leaves sblk[b] for every block, hardmask[b], and the accept masks / entering counts of the blocks it
-// computed itself.  fault != 0 (testing): corrupt one lookup.
+// ------------------------------------------------------------------------------------------------
+// r04: SEGMENTS -- the gap-transfer tables of consecutive prepared blocks composed into one.
+//
+// r03's clock profile of the chain: 22 % of its time were the table lookups of the prepared blocks (815 clocks per
+// block, 75 blocks per permutation of 1M cells), although the tables of a run of prepared blocks are all known before
+// the chain gets there.  The map entry gap -> exit gap of one block is monotone with unit steps, and so is a
+// composition of such maps (with the constant shifts G_j + cnt_j - G_{j+1} between the blocks' guesses in between):
+// the composition is again a bitset of surviving increments.  k_phi_compose builds it on the chip, one workgroup per
+// SEGMENT (<= PHI_SEG_MAX consecutive prepared blocks whose windows are not narrowed by a band edge; a block with a
+// narrowed window is a segment of its own and keeps its own table), by pushing every entry state of the window through
+// the segment's tables.  The chain then pays ONE lookup per segment (every thread evaluates it redundantly from LDS: no
+// hand-over between wavefronts), k_seg_fill -- one wavefront per segment, behind the chain's "unit done" word --
+// fills in the entry states of the blocks inside the segments from the per-block tables, and k_block_exact verifies all
+// of it exactly as before: the composed table of a segment is right or its last block's exit state does not meet the
+// chain's.
+// ------------------------------------------------------------------------------------------------
+#ifndef PHI_SEG_MAX
+#define PHI_SEG_MAX 16        // blocks per segment at most (segments are cut at multiples of this inside a unit)
+#endif
+#define PHI_NS 6              // segments whose tables the chain stages in LDS at once (a run of prepared blocks)
+#define PHI_STAGE_PIECES 64   // 16-byte pieces per side the chain stages: entry gaps up to 8192 (beyond: global memory)
+
+struct PhiSeg {               // one per ring slot, written by k_phi_compose
+    unsigned long long G;     // guessed entry state of the segment's first block
+    int32_t exit0;            // exit state of the segment for entry state G, relative to G
+    uint32_t i_in;            // steps left in G's permutation
+    uint16_t vpos, vneg;      // entry states G - vneg .. G + vpos are covered
+    uint8_t kind;             // 0: the chain computes this block itself, 1: first block of a segment, 2: inside one
+    uint8_t len;              // kind 1: blocks in the segment
+    uint8_t own;              // kind 1: the segment's table is the block's own (tbits), else the composed one (ctbits)
+    uint8_t bad;              // kind 1: the composition left the windows even for the base trajectory (never seen): no lookup
+};
+static_assert(sizeof(PhiSeg) == 24, "PhiSeg layout");
+
+__device__ __forceinline__ bool phi_full(const PhiDesc &d) { return d.prepared && d.w_pos == d.w && d.w_neg == d.w; }
+
+// set bits among the first nbit (1 .. 128) bits of a 16-byte piece (32-bit masks only, see xsl_rr32)
+__device__ __forceinline__ uint32_t phi_piece_rank(const ulonglong2 a, uint32_t nbit)
+{
+    const uint32_t wd[4] = {(uint32_t)a.x, (uint32_t)(a.x >> 32), (uint32_t)a.y, (uint32_t)(a.y >> 32)};
+    uint32_t T = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = 32u * j;
+        const uint32_t m = nbit >= lo + 32u ? 0xffffffffu : (nbit > lo ? ((1u << ((nbit - lo) & 31u)) - 1u) : 0u);
+        T += (uint32_t)__popc(wd[j] & m);
+    }
+    return T;
+}
+
+// Prepare blocks [b0, b1), part 3: segments.  One workgroup per block; the workgroup of a segment's first block
+// composes the segment's table, the others only classify their block.
+__global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+                                                             const unsigned long long *__restrict__ tbits,
+                                                             PhiSeg *__restrict__ seg,
+                                                             unsigned long long *__restrict__ ctbits)
+{
+    static_assert(SCAN_THREADS == 1024 && PHI_W == 16384, "thread t of a side owns entry gaps 32 t .. 32 t + 32");
+    __shared__ ulonglong2 tl[2 * 128];      // the current block's tables: [side][128 pieces]
+    __shared__ uint32_t tpre[2 * 128];      // set bits in front of each piece inside its wavefront's 64 pieces
+    __shared__ uint32_t wtot[4];            // set bits of pieces 0 .. 63 / 64 .. 127 of each side
+    __shared__ uint32_t Uw[2 * PHI_W / 32]; // the block's increments on the signed gap axis: bit PHI_W + d = F(d + 1) - F(d)
+    __shared__ int32_t shLoT, shHiT, shE0;  // first thread of each side that dropped out; exit state of the base
+    const uint64_t b = b0 + blockIdx.x;
+    if (b >= b1) return;
+    const uint32_t r = blockIdx.x, nb = (uint32_t)(b1 - b0), tau = threadIdx.x;
+    const uint64_t slot = b % PHI_RING;
+    const PhiDesc cur = desc[slot];
+    PhiSeg s;
+    s.G = cur.G; s.exit0 = (int32_t)cur.cnt; s.i_in = cur.i_in; s.vpos = cur.w_pos; s.vneg = cur.w_neg;
+    s.kind = 0; s.len = 0; s.own = 1; s.bad = 0;
+    if (!cur.prepared) { if (tau == 0) seg[slot] = s; return; }
+    bool start = r == 0 || (r % PHI_SEG_MAX) == 0 || !phi_full(cur);
+    if (!start) { const PhiDesc prev = desc[(b - 1) % PHI_RING]; start = !phi_full(prev); }
+    if (!start) { s.kind = 2; if (tau == 0) seg[slot] = s; return; }
+    uint32_t len = 1;
+    if (phi_full(cur))
+        while (r + len < nb && ((r + len) % PHI_SEG_MAX) != 0 && phi_full(desc[(b + len) % PHI_RING])) ++len;
+    s.kind = 1; s.len = (uint8_t)len;
+    if (len == 1) { if (tau == 0) seg[slot] = s; return; }   // its own table serves
+
+    // ---- compose: every entry state of the window through the segment's tables ----
+    // Thread (side, t) owns the 33 entry gaps 32 t .. 32 t + 32 of its side, held ASCENDING on the signed state axis
+    // (negative side: st[k] belongs to the gap -(32 t + 32 - k)).  The images of neighbouring states differ by 0 or 1
+    // (monotone, unit steps), so a block maps the thread's states with ONE rank lookup (its lowest state) and one bit of
+    // the block's increment array U per further state:  F(a + 1) - F(a) = U[a - G_j],  U = the negative side's bits
+    // reversed, then the positive side's.  A thread whose states are not all inside a block's window drops out; the
+    // segment then covers the gaps below that thread (the window's rim, 4.5 sigma out: nothing is lost).
+    const uint32_t side = tau >> 9, t = tau & 511u;
+    int32_t st[33];
+#pragma unroll
+    for (int k = 0; k <= 32; ++k) st[k] = side ? -(int32_t)(32u * t + 32u - k) : (int32_t)(32u * t + k);
+    bool ok = true;
+    if (tau == 0) { shLoT = 512; shHiT = 512; }
+    const ulonglong2 *tb2 = reinterpret_cast<const ulonglong2 *>(tbits);
+    for (uint32_t j = 0; j < len; ++j) {
+        const PhiDesc dj = desc[(b + j) % PHI_RING];
+        __syncthreads();     // the previous block's lookups are done (and shLoT / shHiT are set)
+        if (tau < 256) {     // piece (tau & 127) of side (tau >> 7); a wavefront's 64 pieces are half a side
+            const uint32_t piece = tau & 127u;
+            const ulonglong2 v = tb2[((((b + j) % PHI_RING) * 2 + (tau >> 7)) * PHI_WORDS) / 2 + piece];
+            const uint32_t ones = (uint32_t)(__popcll(v.x) + __popcll(v.y));
+            const uint32_t upto = wave_inclusive_scan(ones);
+            tl[tau] = v;
+            tpre[tau] = upto - ones;
+            if ((tau & 63u) == 63u) wtot[tau >> 6] = upto;
+            const uint32_t wd[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+            if (tau < 128) {   // positive side: bit i of the side is U position PHI_W + i
+#pragma unroll
+                for (int m = 0; m < 4; ++m) Uw[PHI_W / 32 + 4 * piece + m] = wd[m];
+            } else {           // negative side: bit i is U position PHI_W - 1 - i
+#pragma unroll
+                for (int m = 0; m < 4; ++m) Uw[PHI_W / 32 - 4 * piece - 1 - m] = __brev(wd[m]);
+            }
+        }
+        __syncthreads();
+        const int32_t rel = (int32_t)(int64_t)(dj.G - cur.G);   // this block's guess, relative to the first one's
+        const int32_t wj = (int32_t)dj.w;
+        if (ok && (st[0] - rel < -wj || st[32] - rel > wj)) {   // (also: gaps beyond the first block's own window)
+            ok = false;
+            atomicMin(side ? &shLoT : &shHiT, (int32_t)t);
+        }
+        if (ok) {
+            const int32_t d0 = st[0] - rel;
+            const bool neg = d0 < 0;
+            const uint32_t idx = (uint32_t)(neg ? -d0 : d0);
+            uint32_t T = 0;
+            if (idx) {
+                const uint32_t piece = (idx - 1u) >> 7, nbit = idx - 128u * piece;
+                const uint32_t row = (neg ? 128u : 0u) + piece;
+                T = tpre[row] + (piece >= 64u ? wtot[neg ? 2 : 0] : 0u) + phi_piece_rank(tl[row], nbit);
+            }
+            int32_t run = rel + (int32_t)dj.cnt + (neg ? -(int32_t)T : (int32_t)T);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int32_t inc = st[k + 1] - st[k];                       // 0 or 1
+                const uint32_t q = (uint32_t)(PHI_W + st[k] - rel);          // U position of the step st[k] -> st[k] + 1
+                const uint32_t bit = (Uw[q >> 5] >> (q & 31u)) & 1u;
+                st[k] = run;
+                run += inc & (int32_t)bit;
+            }
+            st[32] = run;
+        }
+    }
+    if (t == 0 && side == 0) shE0 = ok ? st[0] : (int32_t)0x80000000;
+    __syncthreads();
+    // surviving increments: positive side bit p = exit(p + 1) - exit(p); negative side bit p = exit(-p) - exit(-p - 1)
+    uint32_t word = 0;
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (st[k + 1] != st[k]) word |= 1u << (side ? 31 - k : k);
+    }
+    reinterpret_cast<uint32_t *>(ctbits + (slot * 2 + side) * PHI_WORDS)[t] = word;
+    if (tau == 0) {
+        const int32_t hiT = shHiT, loT = shLoT, e0 = shE0;
+        s.own = 0;
+        if (e0 == (int32_t)0x80000000 || hiT == 0 || loT == 0) { s.bad = 1; s.vpos = 0; s.vneg = 0; }
+        else {
+            const uint32_t vp = 32u * (uint32_t)hiT, vn = 32u * (uint32_t)loT;
+            s.exit0 = e0;
+            s.vpos = (uint16_t)(vp < cur.w ? vp : cur.w);
+            s.vneg = (uint16_t)(vn < cur.w ? vn : cur.w);
+        }
+        seg[slot] = s;
+    }
+}
+
+// Entry states of the blocks inside the segments of blocks [b0, b1) that the chain resolved by ONE lookup (segmode 1):
+// one wavefront per segment walks the per-block tables from the segment's entry state.  Runs behind the chain's
+// "unit done" word; k_block_exact then verifies every block (the last one's exit state must meet the chain's).
+__global__ __launch_bounds__(64) void k_seg_fill(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+                                                 const PhiSeg *__restrict__ seg,
+                                                 const unsigned long long *__restrict__ tbits,
+                                                 const uint8_t *__restrict__ segmode,
+                                                 unsigned long long *__restrict__ sblk, uint8_t *__restrict__ hardmask,
+                                                 unsigned long long *__restrict__ st)
+{
+    const uint64_t b = b0 + blockIdx.x;
+    if (b >= b1 || segmode[b] != 1) return;
+    const uint32_t len = seg[b % PHI_RING].len;
+    const uint32_t lane = threadIdx.x;
+    unsigned long long S = sblk[b];
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint64_t slot = (b + j) % PHI_RING;
+        const PhiDesc d = desc[slot];
+        const int64_t g = (int64_t)S - (int64_t)d.G;
+        const bool neg = g < 0;
+        const uint64_t idx = (uint64_t)(neg ? -g : g);
+        if (!d.prepared || idx > (neg ? d.w_neg : d.w_pos)) {   // the composed table said this could not happen
+            if (lane == 0) atomicOr(st + 2, 32ull);
+            return;
+        }
+        const uint32_t T = idx ? phi_lookup(tbits + (slot * 2 + (neg ? 1 : 0)) * PHI_WORDS, (uint32_t)idx) : 0u;
+        if (lane == 0) { sblk[b + j] = S; hardmask[b + j] = 0; }
+        S = d.G + d.cnt + (neg ? -(long long)T : (long long)T);
+    }
+}
+
+// Chain the exact states through blocks [b0, b1) (one workgroup): a SEGMENT of prepared blocks costs one lookup in
+// its (composed) table, which every thread evaluates for itself from LDS; the other blocks the full in-block fixed
+// point.  While a block is computed, the draws of the next block to compute and the tables of the run of segments
+// before it are already on their way (registers, then LDS).  Leaves sblk[b] for every block it computed and for the
+// first block of every segment (k_seg_fill adds the blocks inside), hardmask[b], segmode[b] and the accept masks /
+// entering counts of the blocks it computed itself.  fault != 0 (testing): corrupt one lookup.
 __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restrict__ raw, uint64_t n_blocks,
                                                         uint32_t n, uint64_t total_steps, uint64_t B0, uint64_t B1,
                                                         uint64_t S_need, const PhiDesc *__restrict__ desc,
                                                         const unsigned long long *__restrict__ tbits,
-                                                        uint8_t *__restrict__ hardmask, int fault,
+                                                        const PhiSeg *__restrict__ seg,
+                                                        const unsigned long long *__restrict__ ctbits,
+                                                        uint8_t *__restrict__ hardmask, uint8_t *__restrict__ segmode, int fault,
                                                         bits_t *__restrict__ acc_bits, uint32_t *__restrict__ enter,
                                                         unsigned long long *__restrict__ sblk,
                                                         unsigned long long *__restrict__ st, uint32_t *__restrict__ flags,
@@ -843,18 +1040,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
 {
     __shared__ BlockShared sh;
     __shared__ uint32_t shReady;
-    __shared__ __align__(16) PhiDesc dsc[PHI_UNIT];
+    __shared__ __align__(8) PhiSeg sg[PHI_UNIT];
     __shared__ uint16_t nxt[PHI_UNIT + 2];  // first block >= i (relative to b0) the chain computes itself
-    __shared__ unsigned long long shS, shB;
-    __shared__ uint32_t shRem;
-    __shared__ ulonglong2 tl[PHI_STAGE * PHI_STAGE_WORDS];  // [staged block][side][64 x 16 B]
-    __shared__ uint32_t tpre[PHI_STAGE * PHI_STAGE_WORDS];  // set bits in front of each 16-byte piece of its row
-    __shared__ int32_t candE[PHI_STAGE][64];                // fast run: exit offset (state - G) per candidate entry gap
-    __shared__ int32_t candBase[PHI_STAGE], candD[PHI_STAGE];
-    __shared__ unsigned long long passS[2];
-    __shared__ uint32_t passB[2], passRem[2];
-    __shared__ unsigned long long runS[PHI_UNIT];           // entry states of the blocks resolved by lookup in this run
-    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    __shared__ ulonglong2 tl[PHI_NS * 2 * PHI_STAGE_PIECES];   // [staged segment][side][64 x 16 B]
+    __shared__ uint32_t tpre[PHI_NS * 2 * PHI_STAGE_PIECES];   // set bits in front of each 16-byte piece of its row
+    static_assert(PHI_NS * 2 * PHI_STAGE_PIECES <= SCAN_THREADS, "one 16-byte piece per thread");
+    __shared__ unsigned long long shS;
+    __shared__ uint32_t shRem, shRel;
+    const uint32_t tau = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tau >> 6));
     const uint32_t M = n - 1, top_mask = mask_of(M);
     uint64_t S = st[0];
     if (S >= total_steps || st[1] != B0 || B1 > n_blocks) {  // job complete, or an earlier launch gave up (uniform)
@@ -864,7 +1058,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     uint32_t parity = 0;
     int failed = 0;
     uint64_t endpos = 0;
-    uint32_t n_easy = 0, n_hard = 0, n_fast = 0, n_runs = 0;
+    uint32_t n_easy = 0, n_hard = 0, n_seg = 0, n_slow = 0;
 #ifdef PHI_PROFILE
     unsigned long long pf_easy = 0, pf_hard = 0;
 #endif
@@ -873,210 +1067,153 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     // one launch chains several launch units (each prepared by its own launches; the host waited for all of them)
     uint32_t unit = unit0;
     int gave_up = 0;
+    const ulonglong2 *tb2 = reinterpret_cast<const ulonglong2 *>(tbits), *ctb2 = reinterpret_cast<const ulonglong2 *>(ctbits);
     for (uint64_t b0 = B0; b0 < B1 && !failed && S < total_steps; b0 += PHI_UNIT, ++unit) {
     const uint64_t b1 = b0 + PHI_UNIT < B1 ? b0 + PHI_UNIT : B1;
     const uint32_t nb = (uint32_t)(b1 - b0);
-    __syncthreads();  // the previous unit's readers of dsc / nxt / tl are done
+    __syncthreads();  // the previous unit's readers of sg / nxt / tl are done
+#ifdef PHI_PROFILE
+    const long long pf_w0 = clock64();
+#endif
     if (tau == 0) shReady = (uint32_t)phi_wait_at_least(flags + 1 + unit % PHI_FLAG_SLOTS, unit + 1, st);
     __syncthreads();
+#ifdef PHI_PROFILE
+    if (tau == 0) atomicAdd(&g_phi_prof[20], (unsigned long long)(clock64() - pf_w0));   // waiting for the unit's preparation
+#endif
     if (shReady) { gave_up = (int)shReady; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the unit's descriptors and tables, written by other kernels
-    if (tau < nb) dsc[tau] = desc[(b0 + tau) % PHI_RING];
+    if (tau < nb) sg[tau] = seg[(b0 + tau) % PHI_RING];
     __syncthreads();
     if (tau <= nb) {
         uint32_t j = tau;
-        while (j < nb && dsc[j].prepared) ++j;
+        while (j < nb && sg[j].kind != 0) ++j;
         nxt[tau] = (uint16_t)j;
     }
     __syncthreads();
-    const ulonglong2 *tb2 = reinterpret_cast<const ulonglong2 *>(tbits);
-    // 16-byte chunk c of a staged run that starts at relative block `first`: block c / 128, side (c % 128) / 64
-#define PHI_STAGE_LOAD(first, len)                                                                         \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                        \
-        const uint32_t cc = tau + SCAN_THREADS * k;                                                        \
-        treg[k] = make_ulonglong2(0ull, 0ull);                                                             \
-        if (cc < (len) * PHI_STAGE_WORDS) {                                                                \
-            const uint64_t slot = (b0 + (first) + cc / PHI_STAGE_WORDS) % PHI_RING;                        \
-            treg[k] = tb2[((slot * 2 + (cc % PHI_STAGE_WORDS) / 64) * PHI_WORDS) / 2 + (cc % 64)];         \
+    // The tables of up to PHI_NS consecutive segments that start at relative block `first` (a run ends at the next block
+    // the chain computes): thread = (staged segment q, side, piece) loads one 16-byte piece into treg.
+#define PHI_STAGE_LOAD(first)                                                                              \
+    {                                                                                                      \
+        treg = make_ulonglong2(0ull, 0ull);                                                                \
+        if (tau < PHI_NS * 2 * PHI_STAGE_PIECES) {                                                         \
+            const uint32_t q = tau / (2 * PHI_STAGE_PIECES), sd = (tau / PHI_STAGE_PIECES) & 1u;           \
+            uint32_t pos = (first);                                                                        \
+            for (uint32_t k = 0; k < q && pos < nb && sg[pos].kind == 1; ++k) pos += sg[pos].len;          \
+            if (pos < nb && sg[pos].kind == 1) {                                                           \
+                const uint64_t slot = (b0 + pos) % PHI_RING;                                               \
+                treg = (sg[pos].own ? tb2 : ctb2)[((slot * 2 + sd) * PHI_WORDS) / 2 + (tau % PHI_STAGE_PIECES)]; \
+            }                                                                                              \
         }                                                                                                  \
     }
-    static_assert(PHI_STAGE * PHI_STAGE_WORDS <= 3 * SCAN_THREADS, "three 16-byte chunks per thread");
-    ulonglong2 treg[3];
+    ulonglong2 treg;
     uint32_t un[SCAN_D];
-    // A SEGMENT is up to PHI_STAGE consecutive prepared blocks [rel, hcap) whose tables are staged in LDS; h is the
-    // next block the chain computes itself (h >= hcap; a long run of prepared blocks is several segments).
-    uint32_t rel = 0, h = nxt[0];
-    uint32_t hcap = h < rel + PHI_STAGE ? h : rel + PHI_STAGE;
-    PHI_STAGE_LOAD(rel, hcap - rel)
+    uint32_t rel = 0, h = nxt[0];   // rel: next block to resolve; h: the next block the chain computes itself (>= rel)
+    PHI_STAGE_LOAD(rel)
     if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
     for (;;) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) {   // a wavefront's 64 pieces are one (block, side) row
-                const uint32_t ones = (uint32_t)(__popcll(treg[k].x) + __popcll(treg[k].y));
-                const uint32_t upto = wave_inclusive_scan(ones);
-                if (tau + SCAN_THREADS * k < PHI_STAGE * PHI_STAGE_WORDS) {
-                    tl[tau + SCAN_THREADS * k] = treg[k];
-                    tpre[tau + SCAN_THREADS * k] = upto - ones;
-                }
-            }
-        // the run goes on behind this segment: its next segment's tables are on their way while this one is resolved
-        const bool more = hcap < h;
-        const uint32_t hcap2 = h < hcap + PHI_STAGE ? h : hcap + PHI_STAGE;
-        if (more) PHI_STAGE_LOAD(hcap, hcap2 - hcap)
+        // (only wavefront 0 reads the staged tables, and it is behind the barrier that follows its lookups: no barrier here)
+        {   // a wavefront's 64 pieces are one (segment, side) row
+            const uint32_t ones = (uint32_t)(__popcll(treg.x) + __popcll(treg.y));
+            const uint32_t upto = wave_inclusive_scan(ones);
+            if (tau < PHI_NS * 2 * PHI_STAGE_PIECES) { tl[tau] = treg; tpre[tau] = upto - ones; }
+        }
         __syncthreads();
-        // ---- fast passes (r02) ----------------------------------------------------------------------------------
-        // A lookup by the lone wavefront 0 is ~1300 clocks of dependent instructions (0.6 us).  The entry gap of the
-        // following blocks is predictable to a few steps (it moves by the known difference of the guesses and shrinks by
-        // about the same fraction per block), so wavefront k resolves block cur + k for 64 CANDIDATE entry gaps around
-        // its prediction, one per lane, and wavefront 0 then only picks, block after block, the lane of the gap that
-        // really occurs (v_readlane, ~10 dependent instructions).  A gap outside a block's candidates ends the pass; the
-        // next pass starts there with the now known gap (its first block always hits).  Every picked value is the
-        // table's own: exactness is unaffected (and verified later like every prepared block).
 #ifdef PHI_PROFILE
         const long long pf_t0 = clock64();
 #endif
-        uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
-        const uint32_t hcap_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)hcap);
-        const uint32_t rel_u = cur;
-        bool stop = false;   // uniform
-        uint32_t pass_par = 0;
-        while (cur < hcap_u && !stop) {
-            const uint32_t left = hcap_u - cur;
-            const uint64_t S_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(S >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)S);
-            const PhiDesc d0 = dsc[cur];
-            const int64_t g0w = (int64_t)S_u - (int64_t)d0.G;
-            const bool neg0 = g0w < 0;
-            const uint64_t idx0 = (uint64_t)(neg0 ? -g0w : g0w);
-            if (idx0 > (neg0 ? d0.w_neg : d0.w_pos)) break;               // outside the prepared window: compute the block
-            if (idx0 > 64 * PHI_STAGE_WORDS) { stop = true; break; }      // beyond the staged bits: the lookup loop below
-            const int32_t g0 = (int32_t)g0w;
-            const uint32_t row0 = cur - rel_u;
-            const uint32_t T0 = idx0 ? phi_lookup_lds(tl + (row0 * 2 + (neg0 ? 1 : 0)) * 64, (uint32_t)idx0) : 0u;
-            // events shrink the gap by about the same FRACTION per block (their number is proportional to the gap)
-            const float keep = idx0 ? (float)T0 / (float)(uint32_t)idx0 : 1.f;
-            if (wave < left) {  // this wavefront's block: cur + wave
-                const uint32_t k = wave;
-                // predicted entry gap: c_{j+1} = keep c_j + (G_j + cnt_j - G_{j+1}), c_0 = g0, unrolled over the lanes
-                const float lk = __logf(keep > 1e-6f ? keep : 1e-6f);
-                float term = lane == 0 ? (float)g0 * __expf((float)k * lk) : 0.f;
-                if (lane < k) {
-                    const PhiDesc a = dsc[cur + lane], bb = dsc[cur + lane + 1];
-                    term += (float)(int32_t)(int64_t)(a.G + a.cnt - bb.G) * __expf((float)(k - 1 - lane) * lk);
-                }
-                // summed in 1/16 steps through the DPP prefix sum (a float butterfly would be six LDS-crossbar round trips)
-                const int32_t fixed = (int32_t)__builtin_rintf(term * 16.f);
-                const float c = (float)(int32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)fixed), 63) * 0.0625f;
-                const PhiDesc dk = dsc[cur + k];
-                const int32_t base = (k ? (int32_t)__builtin_rintf(c) : g0) - 32;
-                const int32_t g = base + (int32_t)lane;
+        // ---- the staged segments, one lookup each, by wavefront 0 (sixteen wavefronts doing the same ~60 dependent
+        // instructions take turns on the four SIMDs: four times the clocks of one) ----
+        if (wave == 0) {
+            bool miss0 = false;
+            for (uint32_t q = 0; q < PHI_NS && rel < nb && sg[rel].kind == 1; ++q) {
+                const PhiSeg sq = sg[rel];
+                const int64_t g = (int64_t)S - (int64_t)sq.G;
                 const bool neg = g < 0;
-                const uint32_t idx = (uint32_t)(neg ? -g : g);
-                const bool ok = dk.prepared && idx <= (neg ? dk.w_neg : dk.w_pos) && idx <= 64 * PHI_STAGE_WORDS;
-                const uint32_t row = (row0 + k) * 2 + (neg ? 1u : 0u);
-                uint32_t T = 0;
-                if (ok && idx) {
-                    const uint32_t piece = (idx - 1u) >> 7, nbit = idx - 128u * piece;  // 1 .. 128 bits of that piece
-                    const ulonglong2 a = tl[row * 64 + piece];
-                    const uint32_t wd[4] = {(uint32_t)a.x, (uint32_t)(a.x >> 32), (uint32_t)a.y, (uint32_t)(a.y >> 32)};
-                    T = tpre[row * 64 + piece];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {   // 32-bit masks only (see xsl_rr32)
-                        const uint32_t lo = 32u * j;
-                        const uint32_t m = nbit >= lo + 32u ? 0xffffffffu : (nbit > lo ? ((1u << (nbit - lo)) - 1u) : 0u);
-                        T += (uint32_t)__popc(wd[j] & m);
-                    }
-                }
-                candE[k][lane] = ok ? (int32_t)dk.cnt + (neg ? -(int32_t)T : (int32_t)T) : (int32_t)0x80000000;
-                if (lane == 0) {
-                    candBase[k] = base;
-                    candD[k] = k + 1 < left ? (int32_t)(int64_t)(dk.G - dsc[cur + k + 1].G) : 0;
-                }
-            }
-            __syncthreads();
-            if (wave == 0) {
-                int32_t vE[PHI_STAGE];
-#pragma unroll
-                for (int k = 0; k < PHI_STAGE; ++k) vE[k] = candE[k][lane];
-                const int32_t vB = candBase[lane & (PHI_STAGE - 1)], vD = candD[lane & (PHI_STAGE - 1)];
-                int32_t g = g0, vg = 0, e_last = 0;
-                uint32_t K = 0;
-                bool live = true;
-#pragma unroll
-                for (int k = 0; k < PHI_STAGE; ++k) {
-                    if (live && (uint32_t)k < left) {   // uniform
-                        const uint32_t l = (uint32_t)(g - __builtin_amdgcn_readlane(vB, k));
-                        int32_t e = (int32_t)0x80000000;
-                        if (l < 64u) e = __builtin_amdgcn_readlane(vE[k], (int)l);
-                        if (e == (int32_t)0x80000000) live = false;
-                        else {
-                            vg = lane == (uint32_t)k ? g : vg;
-                            e_last = e;
-                            K = (uint32_t)k + 1;
-                            g = e + __builtin_amdgcn_readlane(vD, k);
-                        }
-                    }
-                }
-                // K >= 1: the first block's candidates are centred on its real gap, which lies inside its window
-                if (lane < K) runS[cur + lane] = dsc[cur + lane].G + (unsigned long long)(long long)vg;
-                if (lane == 0) {
-                    const PhiDesc dl = dsc[cur + K - 1];
-                    unsigned long long SS = dl.G + (unsigned long long)(long long)e_last;
-                    if (fault && n_easy == 0) SS += 1;  // testing: the verification must catch this
-                    passS[pass_par] = SS; passB[pass_par] = cur + K; passRem[pass_par] = dl.i_in - (uint32_t)e_last;
-                }
-                n_easy += K;
-                n_fast += K;
-                ++n_runs;
-            }
-            __syncthreads();
-            S = passS[pass_par];       // (the other buffer is rewritten only after the next pass's first barrier)
-            rem = passRem[pass_par];
-            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)passB[pass_par]);
-            pass_par ^= 1u;
-        }
-        if (wave == 0) {  // what the fast passes left of [rel, hcap): gaps beyond the staged bits (lookup in global memory)
-            uint32_t r = cur;
-            uint64_t SS = S;
-            uint32_t rr = rem;
-            while (stop && r < hcap) {
-                const PhiDesc dd = dsc[r];
-                const int64_t d = (int64_t)SS - (int64_t)dd.G;
-                const uint64_t idx = (uint64_t)(d < 0 ? -d : d);
-                if (idx > (d < 0 ? dd.w_neg : dd.w_pos)) break;  // outside the prepared window: compute the block
-                const uint32_t side = d < 0 ? 1u : 0u;
+                const uint64_t idx = (uint64_t)(neg ? -g : g);
+                if (sq.bad || idx > (neg ? sq.vneg : sq.vpos)) { miss0 = true; break; }   // outside the segment's window
                 uint32_t T = 0;
                 if (idx) {
-                    if (idx <= 64 * PHI_STAGE_WORDS)
-                        T = phi_lookup_lds(tl + ((r - rel) * 2 + side) * 64, (uint32_t)idx);
-                    else
-                        T = phi_lookup(tbits + (((b0 + r) % PHI_RING) * 2 + side) * PHI_WORDS, (uint32_t)idx);
+                    if (idx <= 128u * PHI_STAGE_PIECES) {
+                        const uint32_t piece = ((uint32_t)idx - 1u) >> 7, nbit = (uint32_t)idx - 128u * piece;
+                        const uint32_t row = (q * 2 + (neg ? 1u : 0u)) * PHI_STAGE_PIECES + piece;
+                        T = tpre[row] + phi_piece_rank(tl[row], nbit);
+                    } else {   // beyond the staged bits (|gap| > 8192: ~3 sigma of the widest window)
+                        const uint64_t slot = (b0 + rel) % PHI_RING;
+                        T = phi_lookup((sq.own ? tbits : ctbits) + (slot * 2 + (neg ? 1 : 0)) * PHI_WORDS, (uint32_t)idx);
+                    }
                 }
-                if (lane == 0) runS[r] = SS;   // flushed to sblk by the whole workgroup after the run
-                SS = dd.G + dd.cnt + (side ? -(int64_t)T : (int64_t)T);
-                if (fault && n_easy == 0) SS += 1;  // testing: the verification must catch this
-                rr = dd.i_in - (uint32_t)(SS - dd.G);  // no trajectory of the window leaves G's permutation
-                ++n_easy;
-                ++r;
+                if (tau == 0) { sblk[b0 + rel] = S; segmode[b0 + rel] = 1; }
+                int64_t e = (int64_t)sq.exit0 + (neg ? -(int64_t)T : (int64_t)T);
+                if (fault && n_easy == 0) e += 1;  // testing: the verification must catch this
+                S = sq.G + (unsigned long long)e;
+                rem = sq.i_in - (uint32_t)e;       // no trajectory of the window leaves G's permutation
+                n_easy += sq.len;
+                ++n_seg;
+                rel += sq.len;
             }
-            if (lane == 0) { shS = SS; shB = r; shRem = rr; }
+            if (tau == 0) { shS = S; shRem = rem; shRel = rel | (miss0 ? 0x80000000u : 0u); }
         }
         __syncthreads();
         S = shS;
         rem = shRem;
-        const uint32_t x = (uint32_t)shB;  // first block not resolved by lookup: hcap, or earlier on a window miss
+        rel = shRel & 0x7fffffffu;
+        const bool miss = (shRel >> 31) != 0;
+#ifdef PHI_PROFILE
+        const long long pf_ts = clock64();
+#endif
+        if (miss) {
+            // The entry state lies outside the segment's window (a band edge narrowed it, or the guess was far off):
+            // its blocks one by one -- the per-block tables from global memory where they cover the state, the fixed
+            // point where they do not.  Rare (about every other permutation at 1M cells), and no slower than r03's path.
+            const uint32_t first = rel, last = rel + sg[rel].len;
+            for (; rel < last && !failed && S < total_steps; ++rel) {
+                const uint64_t bx = b0 + rel, slot = bx % PHI_RING;
+                const PhiDesc d = desc[slot];
+                const int64_t g = (int64_t)S - (int64_t)d.G;
+                const bool neg = g < 0;
+                const uint64_t idx = (uint64_t)(neg ? -g : g);
+                if (d.prepared && idx <= (neg ? d.w_neg : d.w_pos)) {
+                    const uint32_t T = idx ? phi_lookup(tbits + (slot * 2 + (neg ? 1 : 0)) * PHI_WORDS, (uint32_t)idx) : 0u;
+                    if (tau == 0) { sblk[bx] = S; hardmask[bx] = 0; }
+                    S = d.G + d.cnt + (unsigned long long)(neg ? -(long long)T : (long long)T);
+                    rem = d.i_in - (uint32_t)(S - d.G);
+                    ++n_easy;
+                } else {
+                    uint32_t u[SCAN_D];
+                    scan_load(raw, bx * SCAN_BLOCK, tau, u);
+                    ScanRes r;
+                    uint32_t excl, total_cnt;
+                    if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; break; }
+                    acc_bits[bx * SCAN_THREADS + tau] = r.bits;
+                    enter[bx * SCAN_THREADS + tau] = excl;
+                    if (tau == 0) { sblk[bx] = S; hardmask[bx] = 1; }
+                    if (r.end) endpos = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
+                    S += total_cnt;
+                    rem = rem_advance(rem, total_cnt, M);
+                    ++n_hard;
+                }
+            }
+            if (tau == 0) segmode[b0 + first] = 2;   // k_seg_fill has nothing to add here
+            ++n_slow;
+#ifdef PHI_PROFILE
+            if (tau == 0) { atomicAdd(&g_phi_prof[21], (unsigned long long)(clock64() - pf_ts)); atomicAdd(&g_phi_prof[22], 1ull); }
+#endif
+            if (failed || S >= total_steps) break;
+        }
 #ifdef PHI_PROFILE
         const long long pf_t1 = clock64();
         pf_easy += (unsigned long long)(pf_t1 - pf_t0);
 #endif
-        for (uint32_t i = rel + tau; i < x; i += SCAN_THREADS) { sblk[b0 + i] = runS[i]; hardmask[b0 + i] = 0; }
-        if (x >= nb) { rel = nb; break; }
-        if (x == hcap && more) {  // the run's next segment (its tables are in treg already)
-            rel = hcap;
-            hcap = hcap2;
+        if (rel >= nb) { rel = nb; break; }
+        if (sg[rel].kind == 1) {   // the run goes on (more segments than staged at once, or behind a slow path)
+            PHI_STAGE_LOAD(rel)
+#ifdef PHI_PROFILE
+            if (tau == 0) atomicAdd(&g_phi_prof[23], 1ull);   // exposed table loads
+#endif
             continue;
         }
+        // ---- block rel: computed by the chain itself ----
+        const uint32_t x = rel;
         uint32_t u[SCAN_D];
         const uint32_t hN = nxt[x + 1];
         if (x == h) {
@@ -1085,16 +1222,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         } else {
             scan_load(raw, (b0 + x) * SCAN_BLOCK, tau, u);
         }
-        // on their way while block x is computed: the tables of the next segment and the draws of the block after it
-        const uint32_t ncap = hN < x + 1 + PHI_STAGE ? hN : x + 1 + PHI_STAGE;
-        PHI_STAGE_LOAD(x + 1, ncap - (x + 1))
+        // on their way while block x is computed: the tables of the run behind it and the draws of the block after that
+        PHI_STAGE_LOAD(x + 1)
         if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
         ScanRes r;
         uint32_t excl, total_cnt;
 #ifdef PHI_PROFILE
         const uint32_t pf_rem = rem;
         int pf_rounds = 0;
-        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, &pf_rounds) > 0) { failed = 1; rel = x; break; }
+        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, &pf_rounds) > 0) { failed = 1; break; }
         if (tau == 0) {   // computed blocks by the steps left in their permutation: count, clocks of the fixed point, rounds
             const int cls = pf_rem > 98304u ? 0 : pf_rem > 49152u ? 1 : pf_rem > 24576u ? 2 : pf_rem > 12288u ? 3 : 4;
             atomicAdd(&g_phi_prof[cls * 4], 1ull);
@@ -1102,7 +1238,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
             atomicAdd(&g_phi_prof[cls * 4 + 2], (unsigned long long)pf_rounds);
         }
 #else
-        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; rel = x; break; }
+        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; break; }
 #endif
         const uint64_t bx = b0 + x;
         acc_bits[bx * SCAN_THREADS + tau] = r.bits;
@@ -1117,7 +1253,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
 #endif
         rel = x + 1;
         h = hN;
-        hcap = ncap;
         if (S >= total_steps) break;
     }
     b_next = b0 + rel;
@@ -1135,10 +1270,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
 #ifdef PHI_PROFILE
         st[6] += (pf_easy >> 6) | ((pf_hard >> 6) << 32);   // clocks / 64 of thread 0: lookup phases, computed blocks
 #else
-        st[6] += n_fast;  // ... of which by the fast passes
+        st[6] += n_seg;   // segment lookups
 #endif
-        st[7] += n_runs;
-        st[4] += n_easy;  // wavefront 0 counted them
+        st[7] += n_slow;  // segments whose window missed the entry state
+        st[4] += n_easy;
         st[5] += n_hard;
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
         unsigned long long f = 0;  // (k_block_exact of the previous chunk may be raising its own flag right now)
@@ -1414,6 +1549,10 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         SC_TRY(c->pg_tbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
         SC_TRY(c->pg_events.ensure(sizeof(uint16_t) * (size_t)PHI_RING * 2 * PHI_MAX_EV, &c->mem));
         SC_TRY(c->pg_hard.ensure((size_t)n_blocks + 1, &c->mem));
+        SC_TRY(c->pg_seg.ensure(sizeof(PhiSeg) * (size_t)PHI_RING, &c->mem));
+        SC_TRY(c->pg_ctbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
+        SC_TRY(c->pg_segmode.ensure((size_t)n_blocks + 1, &c->mem));
+        SC_HIP(hipMemsetAsync(c->pg_segmode.p, 0, (size_t)n_blocks + 1, s));
         int prio_lo = 0, prio_hi = 0;  // the generator is the critical path of its callers (plain streams if refused)
         const bool prio = getenv("SC_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
         for (hipStream_t &sp : c->stream_pg) {
@@ -1472,6 +1611,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
     SC_HIP(hipMemcpyAsync(range, st + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     const uint64_t target = (uint64_t)p1 * (uint64_t)(job->n - 1);
     uint64_t phi_first = 0, phi_end = 0;
+    unsigned phi_fill_streams = 0;
     if (job->phi) {
         // Blocks granted to this chunk: the expected draws of permutations [0, p1) + ~10 sigma + one block
         // (k_chain raises a flag if they do not complete the chunk); the last chunk takes all blocks.
@@ -1485,6 +1625,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
         const uint64_t g0 = job->B_done;
         const int64_t u_first = job->unit_no;
         uint32_t *flags = c->pg_flags.as<uint32_t>();
+        unsigned fill_streams = 0;
         while (job->B_done < B_end) {
             const uint64_t b0 = job->B_done;
             const uint64_t b1 = b0 + PHI_UNIT < B_end ? b0 + PHI_UNIT : B_end;
@@ -1503,17 +1644,32 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
                                c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
                                c->pg_tbits.as<unsigned long long>());
+            hipLaunchKernelGGL(k_phi_compose, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp, b0, b1,
+                               c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(), c->pg_seg.as<PhiSeg>(),
+                               c->pg_ctbits.as<unsigned long long>());
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(1 + u % PHI_FLAG_SLOTS), (uint32_t)(u + 1));
+            // behind the chain's "unit u done": the entry states of the blocks inside the unit's segments (this stream's
+            // next unit, u + PHI_STREAMS, overwrites the ring slots they are read from and is enqueued behind this)
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(u + 1), st);
+            hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)(b1 - b0)), dim3(64), 0, sp, b0, b1, c->pg_desc.as<PhiDesc>(),
+                               c->pg_seg.as<PhiSeg>(), c->pg_tbits.as<unsigned long long>(), c->pg_segmode.as<uint8_t>(),
+                               c->pg_sblk.as<unsigned long long>(), c->pg_hard.as<uint8_t>(), st);
+            fill_streams |= 1u << (unsigned)(u % PHI_STREAMS);
             job->unit_start[(size_t)(u % 8)] = b0;
             job->B_done = b1;
             job->unit_no = u + 1;
         }
         hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
                            (uint32_t)job->n, job->total_steps, g0, B_end, target,
-                           c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(),
-                           c->pg_hard.as<uint8_t>(), (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
+                           c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(), c->pg_seg.as<PhiSeg>(),
+                           c->pg_ctbits.as<unsigned long long>(), c->pg_hard.as<uint8_t>(), c->pg_segmode.as<uint8_t>(),
+                           (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
                            c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st, flags, (uint32_t)u_first);
         SC_HIP(hipGetLastError());
+        // the verification / expansion of this chunk reads the entry states k_seg_fill leaves on the preparation streams
+        for (unsigned q = 0; q < PHI_STREAMS; ++q)
+            if (fill_streams & (1u << q)) SC_HIP(hipEventRecord(c->pg_ev[q], c->stream_pg[q]));
+        phi_fill_streams = fill_streams;
     } else {
         KernelTimerScope ts(c, SC_K_PERM_SCAN, s);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
@@ -1528,6 +1684,8 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
         SC_HIP(hipEventRecord(c->pg_ev[33], s));
         SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[33], 0));
     }
+    for (unsigned q = 0; q < PHI_STREAMS; ++q)
+        if (phi_fill_streams & (1u << q)) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[q], 0));
     // blocks this launch can have covered: the chunk's expected draws + 1 % + 2 blocks
     const double chunk_perms = (double)(p1 - job->p_done);
     uint64_t max_blocks = (uint64_t)(chunk_perms * job->draws_per_perm * 1.01 / SCAN_BLOCK) + 3;
