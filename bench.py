@@ -360,6 +360,7 @@ def main() -> None:
     # of the resident table scored again.  Inside the pipeline it runs on the CUs it leaves to the generator's side
     # and beside the generator's traffic; this is the kernel's own rate.  Reported as roofline.alone, never as `value`.
     timed_bits = ctx.moran_source_bits()
+    timed_lag_bits = ctx.moran_lag_bits()
     alone = None
     if rank == 0 and len(batches) == 1 and not rehearse and P >= 128 and not args.no_alone:
         ctx.reset_timers()
@@ -369,21 +370,21 @@ def main() -> None:
         if a_cnt:
             alone = (a_ms / a_cnt, 128)
 
-    def kernel_roofline(kern_ms, kern_launches, steps, bits):
+    def kernel_roofline(kern_ms, kern_launches, steps, bits, lag_bits=64):
         """Bytes the scoring kernel's formulation has to move per launch (its algorithmic bytes) over its average
         HIP-event launch time.  (1) per step: one 128-byte row of raw values + one 4-byte index per (permutation,
-        cell, gene group of 128 / 64 / 32 / 16 genes) and the fp64 lag rows of every gene once per launch (a launch =
-        one chunk of permutations x all gene groups).  (2) SURVEY 8(d)'s streaming model (16 B per (permutation, gene,
+        cell, gene group of 128 / 64 / 32 / 16 genes) and the lag rows of every gene once per launch (a launch =
+        one chunk of permutations x all gene groups; fp64, or -- r04, count batches -- the 16-bit neighbour sums).  (2) SURVEY 8(d)'s streaming model (16 B per (permutation, gene,
         cell) + 4 B per (permutation, cell)) as an EFFECTIVE rate: the kernel moves fewer bytes than the model."""
         genes_per_row = {8: 128, 16: 64, 32: 32, 64: 16}[bits]
         per_step = max(kern_launches // max(steps, 1), 1)
         avg = kern_ms / max(kern_launches, 1)
         g_pad = -(-batch // genes_per_row) * genes_per_row * len(batches)
         grp = g_pad // genes_per_row
-        step_bytes = grp * (P * n * (128.0 + 4.0)) + per_step * n * 8.0 * g_pad
+        step_bytes = grp * (P * n * (128.0 + 4.0)) + per_step * n * (lag_bits / 8.0) * g_pad
         ach = step_bytes / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
         eff = (P * G_mine * n * 16.0 + P * n * 4.0) / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
-        return {"genes_per_row": genes_per_row, "launches_per_step": per_step, "avg_ms": avg, "g_pad": g_pad, "groups": grp,
+        return {"genes_per_row": genes_per_row, "lag_bits": lag_bits, "launches_per_step": per_step, "avg_ms": avg, "g_pad": g_pad, "groups": grp,
                 "step_bytes": step_bytes, "launch_bytes": step_bytes / per_step, "achieved": ach, "effective": eff}
 
     # The same step with the gathered operand forced to the wider exact types (after the timed region, rank 0, single
@@ -402,7 +403,7 @@ def main() -> None:
             ctx.sync()
             dt = time.perf_counter() - t1
             k_ms, k_cnt = ctx.kernel_time(_lib.K_MORAN_PERM)
-            rf = kernel_roofline(k_ms, k_cnt, 3, bits_alt)
+            rf = kernel_roofline(k_ms, k_cnt, 3, bits_alt, ctx.moran_lag_bits())
             other_sources[bits_alt] = {
                 "value": G_total * 3 / dt, "ms_per_step": dt / 3 * 1e3, "steps": 3, "source_bits": ctx.moran_source_bits(),
                 "roofline": {"achieved": rf["achieved"], "frac": rf["achieved"] / HBM_PEAK_GBS, "avg_launch_ms": rf["avg_ms"],
@@ -417,7 +418,7 @@ def main() -> None:
         value = G_total * args.steps / elapsed
         source_bits = timed_bits
         kernel_name = "k_moran_score"
-        rf = kernel_roofline(perm_ms, perm_launches, args.steps, source_bits)
+        rf = kernel_roofline(perm_ms, perm_launches, args.steps, source_bits, timed_lag_bits)
         launches_per_step, avg_ms, G_pad, groups = rf["launches_per_step"], rf["avg_ms"], rf["g_pad"], rf["groups"]
         kernel_bytes, achieved, effective = rf["launch_bytes"], rf["achieved"], rf["effective"]
         # (3) PMC counters of the same kernel build, collected by scripts/pmc_traffic.py (separate --pmc passes)
@@ -465,7 +466,7 @@ def main() -> None:
                                                                 "96, 48, 24 permutations; a chunk whose last task holds fewer than 24 would "
                                                                 "take k_moran_score); same arithmetic; the average is over all launches",
                          "avg_launch_ms": avg_ms, "launches": perm_launches,
-                         "algorithmic_bytes_per_launch": kernel_bytes,
+                         "algorithmic_bytes_per_launch": kernel_bytes, "lag_bits": timed_lag_bits,
                          "step_frac": rf["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step_frac_basis": "the same compulsory bytes of one step / ms_per_step / peak: what the whole "
                                             "step (graph, generator, lag, scoring, p-values) sustains",
@@ -478,8 +479,8 @@ def main() -> None:
                          "traffic_source": traffic_note,
                          "alone": None if alone is None else {
                              "launch_ms": alone[0], "permutations": alone[1],
-                             "achieved": (groups * alone[1] * n * 132.0 + n * 8.0 * G_pad) / (alone[0] * 1e-3) / 1e9,
-                             "frac": (groups * alone[1] * n * 132.0 + n * 8.0 * G_pad) / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "achieved": (groups * alone[1] * n * 132.0 + n * (timed_lag_bits / 8.0) * G_pad) / (alone[0] * 1e-3) / 1e9,
+                             "frac": (groups * alone[1] * n * 132.0 + n * (timed_lag_bits / 8.0) * G_pad) / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "the same kernel on the whole chip, no generator beside it (128 permutations of the "
                                      "resident table, after the timed region)"}},
             "breakdown_ms_per_step": {"perm_scan_overlapped": scan_ms / args.steps, "perm_swaps": swap_ms / args.steps,
@@ -487,7 +488,8 @@ def main() -> None:
                                       "lag_kernel": lag_ms / args.steps, "knn_kernel": knn_ms / args.steps},
             "permgen_stats": {"jobs_block_parallel": pg[0], "jobs_sequential": pg[1],
                               "verification_fallbacks_max_over_ranks": fallbacks,
-                              "blocks_prepared": pg[3], "blocks_chain": pg[4]},
+                              "blocks_prepared": pg[3], "blocks_chain": pg[4],
+                              "note": ctx.permgen_note()},
             "device_mem_bytes_rank0": mem_peak,
             "nccl_ranks": comm_ranks,
         }

@@ -75,6 +75,10 @@ int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64
  * scoring call gathered. */
 int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
 int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
+/* Element width of the STREAMED operand (the lag rows, `W @ z` of AC:307,864) of the last scoring call: 16 when an
+ * all-count uint8 batch on an equal-weight graph kept its neighbour sums as the 16-bit integers they are (converted to
+ * the same fp64 values inside the kernel), else 64.  Diagnostic: bench.py prices the kernel's compulsory bytes with it. */
+int sc_ctx_moran_lag_bits(sc_ctx *ctx, int *bits);
 /* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream
  * (results are identical in every mode): 0 = automatic (block-parallel scan for n >= 131072, verified on the
  * device, sequential scan otherwise or when the verification fails), 1 = sequential scan only,

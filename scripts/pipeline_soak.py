@@ -23,7 +23,7 @@ for rep in range(reps):
     out = ctx.moran_seeded(w, P)
     badp = np.flatnonzero((out["sims"] != ref["sims"]).any(axis=1))
     print(f"rep {rep}: state_ok={bool((w == wh).all())} permutations with differing sims: {badp.size} (first {badp[:5].tolist()}) "
-          f"count_ge differs for {int((out['count_ge'] != ref['count_ge']).sum())} genes; permgen {ctx.permgen_stats()}", flush=True)
+          f"count_ge differs for {int((out['count_ge'] != ref['count_ge']).sum())} genes; permgen {ctx.permgen_stats()} {ctx.permgen_note()}", flush=True)
     if badp.size:
         st = ctx.debug_copy(5, 0, 8, np.uint64)
         nb = int(st[1])

@@ -25,7 +25,7 @@ def summarize(name):
 names = sorted({r[2] for r in seg})
 def family(prefix):
     return [n for n in names if n.startswith(prefix) or n.startswith("void " + prefix)]
-for n in ["k_chain", "k_phi_events", "k_phi_tbuild", "k_gate", "k_publish", "k_block_exact", "k_expand"] + family("k_apply_swaps") + family("k_moran_score") + family("k_moran_finalize"):
+for n in ["k_chain", "k_phi_events", "k_phi_tbuild", "k_phi_compose", "k_seg_fill", "k_gate", "k_publish", "k_block_exact", "k_expand"] + family("k_apply_swaps") + family("k_moran_score") + family("k_moran_finalize"):
     summarize(n)
 # chain gap analysis: for each chain kernel, when did its prep (tbuild with same index) end?
 ch=[r for r in seg if r[2]=="k_chain"]; tb=[r for r in seg if r[2]=="k_phi_tbuild"]; evk=[r for r in seg if r[2]=="k_phi_events"]
@@ -38,9 +38,13 @@ for i in range(n):
 if n: print(f"chain idle attributable to late preparation: {wait_prep/1e6:.1f} ms")
 print("chain launches: " + ", ".join(f"{(s_-base)/1e6:.1f}-{(e_-base)/1e6:.1f}" for s_, e_, _ in ch))
 print("events kernel avg %.0f us, tbuild avg %.0f us, chain avg %.0f us" % (sum(e-s for s,e,_ in evk)/len(evk)/1e3, sum(e-s for s,e,_ in tb)/len(tb)/1e3, sum(e-s for s,e,_ in ch)/len(ch)/1e3))
+cmp_ = [r for r in seg if r[2] == "k_phi_compose"]
+if cmp_ and len(cmp_) == len(evk):   # a unit's preparation: from the start of its events kernel to the end of its compose kernel
+    lat = [(c[1] - e[0]) / 1e3 for e, c in zip(sorted(evk), sorted(cmp_))]
+    print("compose kernel avg %.0f us; preparation of a unit (events start -> compose end) avg %.0f us, max %.0f us" % (sum(e-s for s,e,_ in cmp_)/len(cmp_)/1e3, sum(lat)/len(lat), max(lat)))
 print("--- kernels other than generator in the first 100 ms and the last 80 ms of the step")
 end=seg[-1][1]
 for s_,e_,n_ in seg:
-    if n_ in ("k_chain","k_phi_events","k_phi_tbuild","k_gate","k_publish"): continue
+    if n_ in ("k_chain","k_phi_events","k_phi_tbuild","k_phi_compose","k_seg_fill","k_gate","k_publish"): continue
     if (s_-base)/1e6 < 100 or (end-s_)/1e6 < 80:
         print(f"{(s_-base)/1e6:8.2f} -> {(e_-base)/1e6:8.2f}  {n_[:40]}")

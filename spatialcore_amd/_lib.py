@@ -36,6 +36,7 @@ SYMBOLS = {
     "sc_ctx_permgen_note": [_P, POINTER(c_char_p)],
     "sc_ctx_set_moran_source_bits": [_P, c_int],
     "sc_ctx_moran_source_bits": [_P, _P],
+    "sc_ctx_moran_lag_bits": [_P, _P],
     "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
     "sc_debug_copy": [_P, c_int, c_int64, _P, c_int64],
@@ -241,6 +242,12 @@ class Context:
         64 (fp64 kernel)."""
         v = c_int(0)
         _check(self._lib.sc_ctx_moran_source_bits(self._h, byref(v)))
+        return v.value
+
+    def moran_lag_bits(self) -> int:
+        """Element width of the lag rows the last scoring call streamed: 16 (neighbour sums of a count batch) or 64."""
+        v = c_int(0)
+        _check(self._lib.sc_ctx_moran_lag_bits(self._h, byref(v)))
         return v.value
 
     def permgen_stats(self) -> Tuple[int, int, int, int, int]:

@@ -294,6 +294,13 @@ int sc_ctx_moran_source_bits(sc_ctx *c, int *bits)
     return SC_OK;
 }
 
+int sc_ctx_moran_lag_bits(sc_ctx *c, int *bits)
+{
+    SC_REQUIRE(c && bits, SC_ERR_INVALID, "null pointer");
+    *bits = c->lag_u16 ? 16 : 64;
+    return SC_OK;
+}
+
 int sc_ctx_permgen_stats(sc_ctx *c, int64_t *jobs_parallel, int64_t *jobs_sequential, int64_t *fallbacks,
                          int64_t *blocks_prepared, int64_t *blocks_chain)
 {

@@ -128,6 +128,7 @@ struct sc_ctx {
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // the raw values again in the narrowest exact type, one 128-byte row per cell and gene group:
                          // 32 float (float32-exact values), 64 uint16 (counts < 65536) or 128 uint8 (counts < 256) per row
+    bool lag_u16 = false;       // the last moran_prepare left Lag as 16-bit neighbour sums ([group][cell][64 words]; uint8 source only)
     int narrow_bits = 64;       // element width of the narrow copy the last moran_prepare built: 8, 16, 32 (64: none, the fp64 Z tiles are gathered)
     int n_cus = 0;              // compute units of the device (filled on first use)
     int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
@@ -203,6 +204,7 @@ struct PermJob {
     uint64_t B_done = 0;       // blocks covered by the chain launches so far
     uint64_t unit_start[8] = {};  // first block of the last launch units (ring)
     int64_t unit_no = 0;
+    int64_t gate_seen[4] = {};   // per preparation stream: the "units completed by the chain" count its last gate waited for
     int ahead = 1;             // units prepared ahead of the chain
 };
 // A generator job whose chunks are (being) enqueued on the generator's streams while the consumer catches up.

@@ -727,13 +727,19 @@ __global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict
 
 #define SCORE_WAVES 16
 
-template <int BITS, int CB, bool BIG>
+// L16 (BITS == 8 only, r04): the lag operand arrives as the 16-bit neighbour sums k_lag_u8 leaves -- Lag16[group][cell][t][q]
+// = S of genes (16 t + 2 q, + 1) as two uint16 in one word, 256 bytes per cell and 128-gene group instead of 1 KB of fp64
+// -- and becomes the same fp64 values when it is parked in LDS (integers: exact): a quarter of the streamed bytes.
+__device__ __forceinline__ double2 lag16_to_double2(uint32_t v) { return make_double2((double)(v & 0xffffu), (double)(v >> 16)); }
+
+template <int BITS, int CB, bool BIG, bool L16 = false>
 __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
     int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
 {
     static_assert((BITS == 8 || BITS == 16 || BITS == 32 || BITS == 64) && (CB == 4 || CB == 8), "source width / block size");
+    static_assert(!L16 || BITS == 8, "16-bit lag rows belong to the uint8 source");
     constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : BITS == 32 ? 2 : 1;   // 16-gene lag tiles per gene group
     // BITS == 8 (128 genes per row, 16 accumulators per lane): no room for 16 centres in registers -- only launched when
     // every gene of the batch is a lattice gene (centre 0, integer operands: exact).  BITS == 64 gathers rows of the Z
@@ -777,6 +783,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
         const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
         // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
         const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (lane & 7);
+        const uint32_t *lag16_g = reinterpret_cast<const uint32_t *>(Lag) + (int64_t)grp * n * ROW;   // L16: [cell][ROW] words
+        const uint32_t *lsrc16 = lag16_g + (lane % ROW);
         double m[CENTER ? TG : 1][2], acc[TG][2];
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
@@ -790,6 +798,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
 
         int4 ida[NI], idb[NI];
         double2 lg0, lg1, lg2, lg3;   // lag pieces on their way to LDS (as many as NL)
+        uint32_t lh0 = 0, lh1 = 0, lh2 = 0, lh3 = 0;   // ... as 16-bit pairs (L16)
         uint4 xa[CB], xb[CB];
 
         auto load_idx = [&](int4 (&id)[NI], int64_t b) {
@@ -800,9 +809,15 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
         auto load_lag = [&](int64_t b) {
             const int64_t bb = b < nblk ? b : nblk - 1;
             const int64_t row0 = c0 + bb * CB + lcell0;
-            lg0 = lsrc[row0 * 8];
-            if constexpr (NL > 1) lg1 = lsrc[(row0 + CSTEP) * 8];
-            if constexpr (NL > 2) { lg2 = lsrc[(row0 + 2 * CSTEP) * 8]; lg3 = lsrc[(row0 + 3 * CSTEP) * 8]; }
+            if constexpr (L16) {
+                lh0 = lsrc16[row0 * ROW];
+                if constexpr (NL > 1) lh1 = lsrc16[(row0 + CSTEP) * ROW];
+                if constexpr (NL > 2) { lh2 = lsrc16[(row0 + 2 * CSTEP) * ROW]; lh3 = lsrc16[(row0 + 3 * CSTEP) * ROW]; }
+            } else {
+                lg0 = lsrc[row0 * 8];
+                if constexpr (NL > 1) lg1 = lsrc[(row0 + CSTEP) * 8];
+                if constexpr (NL > 2) { lg2 = lsrc[(row0 + 2 * CSTEP) * 8]; lg3 = lsrc[(row0 + 3 * CSTEP) * 8]; }
+            }
         };
         auto gather = [&](uint4 (&x)[CB], const int4 (&id)[NI]) {
 #pragma unroll
@@ -815,9 +830,15 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
         };
         auto park_lag = [&](int buf) {
             double2 *dst = lw + buf * (CB * ROW) + lane;
-            dst[0] = lg0;
-            if constexpr (NL > 1) dst[64] = lg1;
-            if constexpr (NL > 2) { dst[128] = lg2; dst[192] = lg3; }
+            if constexpr (L16) {
+                dst[0] = lag16_to_double2(lh0);
+                if constexpr (NL > 1) dst[64] = lag16_to_double2(lh1);
+                if constexpr (NL > 2) { dst[128] = lag16_to_double2(lh2); dst[192] = lag16_to_double2(lh3); }
+            } else {
+                dst[0] = lg0;
+                if constexpr (NL > 1) dst[64] = lg1;
+                if constexpr (NL > 2) { dst[128] = lg2; dst[192] = lg3; }
+            }
         };
         auto mul_cell = [&](const uint4 &x, const double2 *lr) {
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -884,7 +905,9 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                const double2 l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
+                double2 l;
+                if constexpr (L16) l = lag16_to_double2(lag16_g[j * ROW + t * 8 + q]);
+                else l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
                 double v0, v1;
                 if (BITS == 8) {
                     const uint32_t h = w[t >> 1] >> (16 * (t & 1));
@@ -936,7 +959,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
 #define SCORE_WG_MIN_PERMS 24   // permutations in a chunk's last (partial) task from which the workgroup form is used
 #endif
 
-template <int BITS, int CB, bool BIG>
+template <int BITS, int CB, bool BIG, bool L16 = false>
 __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
     const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
@@ -980,6 +1003,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
         // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
         const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (pid & 7);
+        const uint32_t *lag16_g = reinterpret_cast<const uint32_t *>(Lag) + (int64_t)grp * n * ROW;   // L16: [cell][ROW] words
+        const uint32_t *lsrc16 = lag16_g + (pid % ROW);
         double m[CENTER ? TG : 1][2], acc[TG][2];
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
@@ -993,7 +1018,12 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         const int64_t nblk = nsb * SPS;
 
         double2 lg;
+        uint32_t lh = 0;   // L16: the thread's piece as a pair of 16-bit sums
         uint4 xa[CB], xb[CB];
+        auto park = [&](int buf) {
+            if constexpr (L16) lds_lag[buf][pid] = lag16_to_double2(lh);
+            else lds_lag[buf][pid] = lg;
+        };
 
         auto load_idx = [&](int4 (&id)[NI], int64_t b) {
             const int64_t bb = b < nblk ? b : nblk - 1;   // past the end: a harmless reload of the last block
@@ -1002,7 +1032,8 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         };
         auto load_lag = [&](int64_t sb) {
             const int64_t ss = sb < nsb ? sb : nsb - 1;
-            lg = lsrc[(c0 + ss * SCORE_SB + lcell) * 8];
+            if constexpr (L16) lh = lsrc16[(c0 + ss * SCORE_SB + lcell) * ROW];
+            else lg = lsrc[(c0 + ss * SCORE_SB + lcell) * 8];
         };
         auto gather = [&](uint4 (&x)[CB], const int4 (&id)[NI]) {
 #pragma unroll
@@ -1046,7 +1077,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             for (int c = 0; c < CB; ++c) mul_cell(cur[c], lr + c * ROW);
             __builtin_amdgcn_sched_barrier(0);
             if (k == SPS - 1) {
-                lds_lag[(sb + 1) & 1][pid] = lg;     // (that buffer was last read in super-block sb - 1, before its barrier)
+                park((int)((sb + 1) & 1));           // (that buffer was last read in super-block sb - 1, before its barrier)
                 __syncthreads();
             }
         };
@@ -1057,11 +1088,11 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             // a wavefront beyond the chunk's permutations only carries its pieces of the lag rows into LDS: the same
             // barriers as the scoring loop below, no gathers (the branch is wavefront-uniform and OUTSIDE that loop)
             load_lag(0);
-            lds_lag[0][pid] = lg;
+            park(0);
             __syncthreads();
             for (int64_t sb = 0; sb < nsb; ++sb) {
                 load_lag(sb + 1);
-                lds_lag[(sb + 1) & 1][pid] = lg;
+                park((int)((sb + 1) & 1));
                 __syncthreads();
             }
         } else if (nsb > 0) {
@@ -1072,7 +1103,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             load_idx(id0, 1);
             load_idx(id1, 2);
             if constexpr (SPS == 4) { load_idx(id2, 3); load_idx(id3, 4); }
-            lds_lag[0][pid] = lg;
+            park(0);
             __syncthreads();
             for (int64_t sb = 0; sb < nsb; ++sb) {
                 stage(xa, xb, id0, sb, 0);
@@ -1089,7 +1120,9 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
                 const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                 for (int t = 0; t < TG; ++t) {
-                    const double2 l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
+                    double2 l;
+                    if constexpr (L16) l = lag16_to_double2(lag16_g[j * ROW + t * 8 + q]);
+                    else l = reinterpret_cast<const double2 *>(lag_g + (int64_t)(t < tiles_left ? t : 0) * tile_elems)[j * 8 + q];
                     double v0, v1;
                     if (BITS == 8) {
                         const uint32_t h = w[t >> 1] >> (16 * (t & 1));
@@ -1182,6 +1215,7 @@ static int moran_check(sc_ctx *c, int64_t n_perm, const double *I_out)
 __global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                 const uint4 *__restrict__ narrow, const int32_t *__restrict__ order, int64_t n,
                                                 int tiles16, int64_t tile_elems, double *__restrict__ Lag,
+                                                uint32_t *__restrict__ Lag16 /* non-null: the sums as 16-bit pairs instead */,
                                                 double *__restrict__ partial /* [2][tile][chunk][16] */, int chunks)
 {
     __shared__ double shT[128], shS[128];      // [tile of the group][slot]
@@ -1217,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ in
                 const int k = t >> 1, sh = 16 * (t & 1);
                 const double s0 = (double)((lo[k] >> sh) & 0xffffu), s1 = (double)((hi[k] >> sh) & 0xffffu);
                 const double x0 = (double)((xo[k] >> sh) & 0xffu), x1 = (double)((xo[k] >> (sh + 8)) & 0xffu);
-                if (t < tiles_left)
+                if (Lag16) Lag16[((int64_t)grp * n + cell) * 64 + t * 8 + q] = ((lo[k] >> sh) & 0xffffu) | (((hi[k] >> sh) & 0xffffu) << 16);
+                else if (t < tiles_left)
                     reinterpret_cast<double2 *>(Lag + (int64_t)(8 * grp + t) * tile_elems)[cell * 8 + q] = make_double2(s0, s1);
                 accS[2 * t] += s0; accS[2 * t + 1] += s1;
                 accT[2 * t] = fma(x0, s0, accT[2 * t]); accT[2 * t + 1] = fma(x1, s1, accT[2 * t + 1]);
@@ -1330,10 +1365,17 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     SC_TRY(c->g_corr.ensure(gb, &c->mem));
     SC_TRY(c->g_thr.ensure(gb, &c->mem));
     SC_TRY(c->g_I.ensure(gb, &c->mem));
-    SC_TRY(c->Lag.ensure((size_t)T * n * SC_TILE * sizeof(double), &c->mem));
+    {   // fp64 tiles, or (uint8 batches) 256 bytes of 16-bit sums per cell and 128-gene group -- more than ONE fp64 tile
+        const size_t tiles_b = (size_t)T * n * SC_TILE * sizeof(double), sums16_b = (size_t)ceil_div64(T, 8) * n * 256;
+        SC_TRY(c->Lag.ensure(tiles_b > sums16_b ? tiles_b : sums16_b, &c->mem));
+    }
     // an all-lattice uint8 batch (count data on a kNN graph): narrow copy first, then neighbour sums + both column sums
     // from the uint8 rows in one pass (k_lag_u8); no Z tiles at all (the lattice operand IS the raw value)
     const bool u8_prelude = n_perm > 0 && bits == 8 && lat_all && c->g_deg_max <= 257 && !getenv("SC_NO_U8_PRELUDE");
+    // ... with the neighbour sums kept as the 16-bit integers they are (r04): a quarter of the bytes k_lag_u8 writes in the
+    // serial prelude and of the lag bytes every scoring launch streams (SC_LAG_FP64: the r03 form, for A/B runs)
+    const bool lag16 = u8_prelude && !getenv("SC_LAG_FP64");
+    c->lag_u16 = lag16;
     if (u8_prelude) {
         c->lm_valid = false;   // (Lag is about to be rewritten)
         SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
@@ -1346,7 +1388,8 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
             KernelTimerScope ts(c, SC_K_LAG);
             hipLaunchKernelGGL(k_lag_u8, dim3((unsigned)align_up64(chunks, 8), (unsigned)ceil_div64(T, 8)), dim3(256), 0, c->stream,
                                c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), c->X32.as<uint4>(), order, n, (int)T,
-                               (int64_t)n * SC_TILE, c->Lag.as<double>(), c->red_tmp.as<double>(), chunks);
+                               (int64_t)n * SC_TILE, c->Lag.as<double>(), lag16 ? c->Lag.as<uint32_t>() : nullptr,
+                               c->red_tmp.as<double>(), chunks);
         }
         hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)T), dim3(SC_TILE), 0, c->stream, c->red_tmp.as<double>(),
                            c->g_Inum.as<double>(), (double *)nullptr, chunks, 1.0);
@@ -1444,7 +1487,7 @@ static int moran_table_is_bijective(sc_ctx *c, int64_t n_perm, bool *bijective)
     return SC_OK;
 }
 
-template <int BITS, int CB, bool BIG>
+template <int BITS, int CB, bool BIG, bool L16 = false>
 static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int cnt, int64_t cps, int splits, int groups)
 {
     static const bool private_lag = getenv("SC_SCORE_PRIVATE_LAG") != nullptr;   // development: the r02 form, for A/B runs
@@ -1459,13 +1502,13 @@ static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int 
         // (r03 measured the grid rounded to whole rounds of tasks -- 1956 tasks are 13 rounds on 160 workgroups, 12 on 163,
         // and 151 suffice for 13: the launches were 3 % shorter with 163, the generator 4 % slower with 3 compute units
         // fewer, the step the same within its noise either way, and with 151 as well.  Not kept.)
-        hipLaunchKernelGGL((k_moran_score_wg<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
+        hipLaunchKernelGGL((k_moran_score_wg<BITS, CB, BIG, L16>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
                            c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
                            c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
                            splits, groups);
         return;
     }
-    hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
+    hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG, L16>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
                        c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
                        c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
                        splits, groups);
@@ -1502,7 +1545,8 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
             // (8 cells per stage were measured for the narrow sources too: under the 128-VGPR cap of the 1024-thread form they spill)
-            if (bits == 8) launch_score<8, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            if (bits == 8 && c->lag_u16) launch_score<8, 4, false, true>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            else if (bits == 8) launch_score<8, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (bits == 16) launch_score<16, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (bits == 32) launch_score<32, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (!big) launch_score<64, 8, false>(c, wgs, c->Z.as<uint4>(), p0, cnt, cps, splits, groups);

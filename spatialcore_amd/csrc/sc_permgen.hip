@@ -497,7 +497,14 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
 #define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
                                   // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
                                   // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
-#define PHI_RING 2048             // table ring slots (> PHI_AHEAD_MAX + 2 units)
+#define PHI_RING 4096             // table ring slots: EIGHT units.  Units are cut at chunk ends, so a short unit shifts the ring
+                                  // positions of its successors, and unit v + 5 can then land on slots of unit v.  The chain is
+                                  // done with unit v by then (k_gate), but k_seg_fill(v) -- which runs behind the chain on stream
+                                  // v % 4 -- need not be: with four units of slots, a fill starved of compute units for a
+                                  // millisecond read descriptors that unit v + 5's preparation had overwritten (seen as a
+                                  // verification fallback when the scoring kernel left 64 or 32 CUs).  With eight, the first
+                                  // unit on ANOTHER stream that can reach v's slots is v + 9, whose gate (chain done with unit
+                                  // >= v + 5) implies publish(v + 4), which sits behind fill(v) in stream v % 4.
 #define PHI_STREAMS 4             // preparation streams (units rotate over them)
 #define PHI_MIN_N (1 << 17)       // below this every block holds a band crossing: sequential form
 
@@ -873,10 +880,9 @@ __device__ __forceinline__ uint32_t phi_piece_rank(const ulonglong2 a, uint32_t 
 
 // Prepare blocks [b0, b1), part 3: segments.  One workgroup per block; the workgroup of a segment's first block
 // composes the segment's table, the others only classify their block.
-__global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
-                                                             const unsigned long long *__restrict__ tbits,
-                                                             PhiSeg *__restrict__ seg,
-                                                             unsigned long long *__restrict__ ctbits)
+__device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+                                                  const unsigned long long *__restrict__ tbits, PhiSeg *__restrict__ seg,
+                                                  unsigned long long *__restrict__ ctbits)
 {
     static_assert(SCAN_THREADS == 1024 && PHI_W == 16384, "thread t of a side owns entry gaps 32 t .. 32 t + 32");
     __shared__ ulonglong2 tl[2 * 128];      // the current block's tables: [side][128 pieces]
@@ -987,6 +993,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, uint6
         }
         seg[slot] = s;
     }
+}
+
+// (r04 measured and dropped: the unit published by the LAST workgroup of this kernel -- a device-scope release per
+// workgroup, i.e. a write-back of the XCD's L2 512 times per unit: generator alone 119 -> 144 ms, bench step 167 -> 214 ms.
+// The kernel boundary in front of k_publish does that once.)
+__global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+                                                             const unsigned long long *__restrict__ tbits,
+                                                             PhiSeg *__restrict__ seg,
+                                                             unsigned long long *__restrict__ ctbits)
+{
+    phi_compose_block(b0, b1, desc, tbits, seg, ctbits);
 }
 
 // Entry states of the blocks inside the segments of blocks [b0, b1) that the chain resolved by ONE lookup (segmode 1):
@@ -1537,6 +1554,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
     SC_TRY(c->pg_sblk.ensure(sizeof(unsigned long long) * (size_t)(n_blocks + 1), &c->mem));
     job->phi = permgen_is_block_parallel(c, n);
     job->B_done = 0; job->unit_no = 0;
+    for (int64_t &g : job->gate_seen) g = 0;
     job->ahead = c->pg_ahead >= 1 && c->pg_ahead <= PHI_AHEAD_MAX ? c->pg_ahead : 1;
     if (job->phi && !c->pg_probed) {   // first block-parallel job of this context: can its streams overlap at all?
         for (hipStream_t &sp : c->stream_pg)
@@ -1584,8 +1602,9 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
             st0[0] = 1;
         }
     }
-    SC_TRY(c->pg_flags.ensure(sizeof(uint32_t) * (1 + PHI_FLAG_SLOTS), &c->mem));
-    SC_HIP(hipMemsetAsync(c->pg_flags.p, 0, sizeof(uint32_t) * (1 + PHI_FLAG_SLOTS), s));
+    // [0] units the chain has completed, [1 .. 16] "unit prepared" words
+    SC_TRY(c->pg_flags.ensure(sizeof(uint32_t) * (1 + 2 * PHI_FLAG_SLOTS), &c->mem));
+    SC_HIP(hipMemsetAsync(c->pg_flags.p, 0, sizeof(uint32_t) * (1 + 2 * PHI_FLAG_SLOTS), s));
     SC_HIP(hipMemcpyAsync(c->pg_out.p, st0, sizeof(st0), hipMemcpyHostToDevice, s));
     SC_HIP(hipMemcpyAsync(c->pg_sblk.p, st0, sizeof(unsigned long long), hipMemcpyHostToDevice, s));  // state at block 0
     SC_HIP(hipStreamSynchronize(s));  // st0 / j0 are stack variables
@@ -1636,7 +1655,9 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             const int64_t dep = u - job->ahead - 1;
             const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
             if (u < PHI_STREAMS) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
-            if (dep >= 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(dep + 1), st);
+            // (a gate in front of this stream's last k_seg_fill has waited for the same or a later "unit done" already)
+            if (dep >= 0 && dep + 1 > job->gate_seen[(size_t)(u % PHI_STREAMS)])
+                hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(dep + 1), st);
             hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
                                c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0,
                                b1, ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
@@ -1651,6 +1672,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             // behind the chain's "unit u done": the entry states of the blocks inside the unit's segments (this stream's
             // next unit, u + PHI_STREAMS, overwrites the ring slots they are read from and is enqueued behind this)
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(u + 1), st);
+            job->gate_seen[(size_t)(u % PHI_STREAMS)] = u + 1;
             hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)(b1 - b0)), dim3(64), 0, sp, b0, b1, c->pg_desc.as<PhiDesc>(),
                                c->pg_seg.as<PhiSeg>(), c->pg_tbits.as<unsigned long long>(), c->pg_segmode.as<uint8_t>(),
                                c->pg_sblk.as<unsigned long long>(), c->pg_hard.as<uint8_t>(), st);
@@ -1752,6 +1774,12 @@ int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6)
                          "the sequential scan (same results); sc_ctx_set_permgen_mode(ctx, 0) re-arms the block-parallel form";
         }
         sc_set_error("sc_perm_generate: block-parallel scan failed its verification (flags %llu)", st[2]);
+        if (!(st[2] & 24ull)) {   // (a one-off: the context stays on the block-parallel form, but the event is on record)
+            char buf[200];
+            snprintf(buf, sizeof(buf), "a block-parallel permutation job failed its verification (flags %llu) and was rerun with the "
+                     "sequential scan (same results)", st[2]);
+            c->pg_note = buf;
+        }
         return SC_PERMGEN_RETRY;
     }
     SC_REQUIRE(st[2] == 0, SC_ERR_STATE, "sc_perm_generate: rejection scan did not converge");
