@@ -90,6 +90,16 @@ int sc_ctx_set_permgen_mode(sc_ctx *ctx, int mode);
  * the context probes that once (5 rounds of 5-ms waits at worst), falls back to the sequential scan with identical
  * results, and leaves the reason here.  sc_ctx_set_permgen_mode re-arms the probe. */
 int sc_ctx_permgen_note(sc_ctx *ctx, const char **message);
+/* The same question asked up front instead of discovered inside the first job (spatialcore_amd.init()): probe the
+ * context's generator streams now; *concurrent = 1 when they overlap (the block-parallel form is available),
+ * *hw_queues_requested = the GPU_MAX_HW_QUEUES value in this process's environment (0: unset).  The reference has no
+ * counterpart (single process, no device: AC:580 n_jobs=1); SURVEY section 5 "failure detection": a degradation must
+ * surface like an error does. */
+int sc_ctx_probe_streams(sc_ctx *ctx, int *concurrent, int *hw_queues_requested);
+/* The scan form a permutation job of length n takes on this context right now, in words -- "block-parallel",
+ * "sequential (...)" or "sequential: <reason>" -- for the provenance entry the drop-in functions append
+ * (src/spatialcore/core/metadata.py:49-77).  Valid until the next call of this function on the context. */
+int sc_ctx_permgen_form(sc_ctx *ctx, int64_t n, const char **form);
 /* Completed generator jobs by scan form, how often the block-parallel form failed its verification and the
  * job was rerun sequentially (0 unless mode 2 injected a fault), and for the block-parallel jobs (failed ones
  * included) the 16384-draw blocks resolved by a prepared table lookup / computed by the chain workgroup itself. */

@@ -48,7 +48,7 @@ def build_c(force: bool = False) -> str:
 def clib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("SC_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (SC_ORACLE_LIB: the sanitizer build)
         if not os.path.exists(so):
             build_c()
         _LIB = ctypes.CDLL(so)

@@ -42,9 +42,13 @@ cmp_ = [r for r in seg if r[2] == "k_phi_compose"]
 if cmp_ and len(cmp_) == len(evk):   # a unit's preparation: from the start of its events kernel to the end of its compose kernel
     lat = [(c[1] - e[0]) / 1e3 for e, c in zip(sorted(evk), sorted(cmp_))]
     print("compose kernel avg %.0f us; preparation of a unit (events start -> compose end) avg %.0f us, max %.0f us" % (sum(e-s for s,e,_ in cmp_)/len(cmp_)/1e3, sum(lat)/len(lat), max(lat)))
+for fam in ("k_apply_swaps", "k_moran_score", "k_block_exact", "k_expand"):
+    for nme in family(fam) or ([fam] if fam in names else []):
+        ks = [r for r in seg if r[2] == nme]
+        print(f"{nme[:34]} launches: " + ", ".join(f"{(s_-base)/1e6:.1f}-{(e_-base)/1e6:.1f}" for s_, e_, _ in ks))
 print("--- kernels other than generator in the first 100 ms and the last 80 ms of the step")
 end=seg[-1][1]
 for s_,e_,n_ in seg:
     if n_ in ("k_chain","k_phi_events","k_phi_tbuild","k_phi_compose","k_seg_fill","k_gate","k_publish"): continue
-    if (s_-base)/1e6 < 100 or (end-s_)/1e6 < 80:
+    if (s_-base)/1e6 < 45 or (end-s_)/1e6 < 30:
         print(f"{(s_-base)/1e6:8.2f} -> {(e_-base)/1e6:8.2f}  {n_[:40]}")

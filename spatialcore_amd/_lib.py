@@ -15,7 +15,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspatialcore_hip.so")
+# (SPATIALCORE_HIP_LIB: another build of the same library -- the sanitizer build of `make asan`, a variant of scripts/build_variant.sh)
+LIB_PATH = os.environ.get("SPATIALCORE_HIP_LIB") or os.path.join(_HERE, "libspatialcore_hip.so")
 
 SC_OK, SC_ERR_INVALID, SC_ERR_STATE, SC_ERR_HIP, SC_ERR_NOMEM, SC_ERR_EMPTY = 0, 1, 2, 3, 4, 5
 SC_F32, SC_F64 = 0, 1
@@ -34,6 +35,8 @@ SYMBOLS = {
     "sc_ctx_set_timing": [_P, c_int],
     "sc_ctx_set_permgen_mode": [_P, c_int],
     "sc_ctx_permgen_note": [_P, POINTER(c_char_p)],
+    "sc_ctx_probe_streams": [_P, _P, _P],
+    "sc_ctx_permgen_form": [_P, c_int64, POINTER(c_char_p)],
     "sc_ctx_set_moran_source_bits": [_P, c_int],
     "sc_ctx_moran_source_bits": [_P, _P],
     "sc_ctx_moran_lag_bits": [_P, _P],
@@ -268,6 +271,20 @@ class Context:
 
             get_logger("device").warning(note)
         return note
+
+    def probe_streams(self) -> Tuple[bool, int]:
+        """(the generator's streams run concurrently, GPU_MAX_HW_QUEUES as this process's environment has it; 0 = unset)."""
+        ok, q = c_int(0), c_int(0)
+        _check(self._lib.sc_ctx_probe_streams(self._h, byref(ok), byref(q)))
+        self.permgen_note()
+        return bool(ok.value), q.value
+
+    def permgen_form(self, n: int) -> str:
+        """Which scan a permutation job of length n takes right now: "block-parallel", "sequential (...)" or
+        "sequential: <reason>" -- recorded in the provenance entry of every drop-in call that draws permutations."""
+        msg = c_char_p()
+        _check(self._lib.sc_ctx_permgen_form(self._h, int(n), byref(msg)))
+        return (msg.value or b"").decode("utf-8", "replace")
 
     def debug_copy(self, which: int, offset_bytes: int, count: int, dtype) -> np.ndarray:
         out = np.empty(count, dtype=dtype)

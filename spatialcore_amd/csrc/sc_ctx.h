@@ -76,6 +76,7 @@ struct sc_ctx {
                                       // later jobs take the sequential scan at once instead of waiting 10 s again
     bool pg_probed = false;           // the stream-concurrency probe ran (once per context, before the first block-parallel job)
     std::string pg_note;              // why the generator left the block-parallel form, if it did (sc_ctx_permgen_note)
+    std::string pg_form;              // scratch of sc_ctx_permgen_form
     int pg_ahead = 1;                 // launch units the preparation runs ahead of the chain (callers that share the chip raise it)
     int64_t pg_jobs_parallel = 0, pg_jobs_sequential = 0, pg_fallbacks = 0;  // generator jobs by scan form
     int64_t pg_blocks_prepared = 0, pg_blocks_chain = 0;  // block-parallel jobs: blocks resolved by table lookup / by the chain workgroup

@@ -813,6 +813,38 @@ static int permgen_probe_streams(sc_ctx *c, hipStream_t chain_stream)
     return SC_OK;
 }
 
+// ---- r04: the generator's form, asked for instead of discovered (sc_init / spatialcore_amd.init) ----
+// Probe the context's generator streams NOW (the first block-parallel job would do it otherwise) and report whether they
+// run concurrently, together with the hardware-queue request the runtime saw when it initialised.
+extern "C" int sc_ctx_probe_streams(sc_ctx *c, int *concurrent, int *hw_queues_requested)
+{
+    SC_REQUIRE(c && concurrent, SC_ERR_INVALID, "sc_ctx_probe_streams: null pointer");
+    SC_HIP(hipSetDevice(c->device));
+    if (!c->stream2) SC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (hipStream_t &sp : c->stream_pg)
+        if (!sp) SC_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+    SC_TRY(permgen_probe_streams(c, c->stream2));
+    *concurrent = c->pg_streams_serial ? 0 : 1;
+    if (hw_queues_requested) {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        *hw_queues_requested = q ? atoi(q) : 0;   // 0: unset (the runtime's default of 4)
+    }
+    return SC_OK;
+}
+
+// Which scan a permutation job of length n takes on this context right now, in words (for provenance records).
+extern "C" int sc_ctx_permgen_form(sc_ctx *c, int64_t n, const char **form)
+{
+    SC_REQUIRE(c && form, SC_ERR_INVALID, "sc_ctx_permgen_form: null pointer");
+    if (n < PHI_MIN_N) c->pg_form = "sequential (permutations shorter than 131072: every block holds a band change)";
+    else if (c->pg_mode == 1) c->pg_form = "sequential (sc_ctx_set_permgen_mode 1)";
+    else if (c->pg_streams_serial) c->pg_form = "sequential: " + c->pg_note;
+    else if (!c->pg_note.empty()) c->pg_form = "block-parallel; " + c->pg_note;
+    else c->pg_form = "block-parallel";
+    *form = c->pg_form.c_str();
+    return SC_OK;
+}
+
 #ifdef PHI_PROFILE
 int sc_permgen_profile(unsigned long long *out32, int reset)
 {

@@ -428,6 +428,7 @@ def _morans_i_on_device(adata, ctx, coords, gene_names, layer, n_neighbors, n_pe
             "use_existing_graph": use_existing_graph,
             "seed": seed,
             "backend": "hip_gfx950",
+            "permgen_form": ctx.permgen_form(n_cells) if n_permutations > 0 else None,
         },
         outputs={"uns": key_added},
     )
@@ -722,6 +723,7 @@ def local_morans_i(
             "fdr_correction": fdr_correction,
             "alpha": alpha,
             "seed": seed,
+            "permgen_form": ctx.permgen_form(n_cells) if n_permutations > 0 else None,
         },
         outputs={
             "obsm_I": f"{key_added}_I",
@@ -861,6 +863,7 @@ def lees_l_local(
             "significance_filter": significance_filter,
             "alpha": alpha,
             "seed": seed,
+            "permgen_form": ctx.permgen_form(adata.n_obs) if n_permutations > 0 else None,
         },
         outputs={"obs_keys": [f"{k}_lees_l" for k in pair_keys[:5]],
                  "uns_keys": [f"{k}_lees_l_params" for k in pair_keys[:5]]},

@@ -240,7 +240,9 @@ def neighborhood_enrichment(
         function_name="neighborhood_enrichment",
         parameters={"celltype_column": celltype_column, "method": method, "k": k if method == "knn" else None,
                     "radius": radius if method == "radius" else None, "n_permutations": n_permutations,
-                    "seed": seed, "spatial_key": spatial_key, "rng": rng},
+                    "seed": seed, "spatial_key": spatial_key, "rng": rng,
+                    "permgen_form": (ctx.permgen_form(n_cells) if rng == "numpy" else "counter-based (philox)")
+                                    if n_permutations > 0 else None},
         outputs={"uns": key_added, "n_celltypes": T, "n_cells": n_cells},
     )
     return adata

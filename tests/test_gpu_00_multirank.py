@@ -230,3 +230,81 @@ def test_generator_without_concurrent_streams_uses_the_sequential_scan(tmp_path)
     assert (par, seq) == (0, 2) and fallbacks in (0, 1), stats    # 0: caught by the probe; 1: by a give-up inside the first job
     assert "sequential scan" in note and "GPU_MAX_HW_QUEUES=2" in note or fallbacks == 1, note
     assert first < 6.0 and second < 5.0, stats      # no 10-s stall any more
+
+
+_INIT_WORKER = r"""
+import os, sys, logging, io
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import spatialcore_amd
+from spatialcore_amd import _lib
+buf = io.StringIO()
+logging.getLogger("spatialcore").addHandler(logging.StreamHandler(buf))
+rep = spatialcore_amd.init()
+print("REPORT", rep["hw_queues_requested"], int(rep["streams_concurrent"]), rep["generator"].replace("\n", " "), flush=True)
+from conftest import make_adata, synth
+from spatialcore_amd.spatial import morans_i
+coords, X = synth(140001, 6, 3, dtype=np.float32)
+ad = make_adata(coords, X)
+morans_i(ad, n_neighbors=6, n_permutations=40, seed=2)
+op = ad.uns["spatialcore_metadata"]["operations"][-1]
+print("FORM", op["parameters"]["permgen_form"].replace("\n", " "), flush=True)
+print("PVAL", " ".join(repr(float(v)) for v in ad.uns["morans_i"]["p_value"].values), flush=True)
+print("WARNED", int("sequential scan" in buf.getvalue()), flush=True)
+"""
+
+
+def _run_init_worker(tmp_path, **env_extra):
+    script = tmp_path / "init_worker.py"
+    script.write_text(_INIT_WORKER.format(root=ROOT))
+    run = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    return {ln.split()[0]: ln.split(None, 1)[1] for ln in run.stdout.splitlines() if ln.split() and ln.split()[0] in ("REPORT", "FORM", "PVAL", "WARNED")}
+
+
+def test_init_reports_the_generator_form_and_every_call_records_it(tmp_path):
+    """r04: the fast path must not depend silently on who initialised HIP first.
+    spatialcore_amd.init() measures whether the generator's streams overlap and says which form it will take;
+    morans_i records the form in its provenance entry.  Same p-values either way; a process that cannot overlap
+    its streams (two hardware queues) is told so: report, warning on the logger, metadata."""
+    fast = _run_init_worker(tmp_path)
+    q, ok, gen = fast["REPORT"].split(None, 2)
+    assert int(q) == 24 and int(ok) == 1 and gen == "block-parallel", fast
+    assert fast["FORM"] == "block-parallel" and fast["WARNED"] == "0", fast
+    slow = _run_init_worker(tmp_path, GPU_MAX_HW_QUEUES="2")
+    q, ok, gen = slow["REPORT"].split(None, 2)
+    if int(ok) == 1:
+        pytest.skip("the runtime ran the streams concurrently on two hardware queues: nothing to report")
+    assert int(q) == 2 and gen.startswith("sequential: ") and "GPU_MAX_HW_QUEUES=2" in gen, slow
+    assert slow["FORM"].startswith("sequential: ") and slow["WARNED"] == "1", slow
+    assert slow["PVAL"] == fast["PVAL"]                      # identical results
+
+
+def test_three_live_contexts_agree_and_say_which_form_they_took():
+    """Three contexts in one process have ~33 streams for the 24 hardware queues the library asks for: the third one's
+    generator streams may share queues.  Whatever each context's probe finds, the tables are numpy's, and a context that
+    took the sequential scan says so (note + form) instead of being silently slower."""
+    from spatialcore_amd import _lib
+
+    n, P = 140001, 6
+    want = _lib.perm_numpy_host(_lib.rng_state_words(np.random.default_rng(12)), n, P)
+    ctxs = [_lib.Context(0) for _ in range(3)]
+    try:
+        forms = []
+        for c in ctxs:
+            c.knn(np.random.default_rng(1).uniform(0, 100, (500, 2)), 4, fetch=False)     # (its other streams exist too)
+            ok, queues = c.probe_streams()
+            got = c.generate_permutations(_lib.rng_state_words(np.random.default_rng(12)), n, P, fetch=True)
+            np.testing.assert_array_equal(got, want)
+            par, seq = c.permgen_stats()[:2]
+            form = c.permgen_form(n)
+            forms.append(form)
+            if ok:
+                assert (par, seq) == (1, 0) and form == "block-parallel", (form, par, seq)
+            else:
+                assert (par, seq) == (0, 1) and form.startswith("sequential: ") and c.permgen_note(), (form, par, seq)
+        assert forms[0] == "block-parallel", forms      # the first context always has its queues to itself
+    finally:
+        for c in ctxs:
+            c.close()

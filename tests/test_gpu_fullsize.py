@@ -420,3 +420,85 @@ def test_config4_at_size_enrichment_k30(big, oracle):
     assert (ge >= first).all() and (ge <= first + (P - 512)).all()
     with np.errstate(invalid="ignore"):
         assert np.nanmax(np.abs(res["zscore"])) < 8              # labels are independent of position: no enrichment
+
+
+def test_config3_one_ranks_full_share_5m_cells_250_genes_p1000(oracle):
+    """BASELINE configs[3] as ONE of the 8 ranks runs it (r04): 5M cells, its 250 of the 2000 genes,
+    all 1000 numpy-exact permutations, in one sc_moran_seeded call (124-133 GB of the 288).  Checked: block-parallel
+    generator without fallback; final generator state == the host generator's after 1000 x 5M Fisher-Yates steps; the
+    last permutation re-scored from the HOST generator's row bit-equal to the pipeline's; observed I and the last
+    permutation's statistic of two genes against the oracle (CSR sweep / gather form on the device's own -- elsewhere
+    tree-checked -- neighbour lists); counts self-consistent; memory bound."""
+    from scipy.sparse import csr_matrix
+
+    from spatialcore_amd import _lib
+
+    n, G, P = 5_000_000, 250, 1000
+    rng = np.random.default_rng(21)
+    coords = rng.uniform(0, np.sqrt(n) * 10.0, (n, 2))
+    X = rng.integers(0, 4, (n, G), dtype=np.uint8).astype(np.float32)      # counts 0 .. 3 (uint8 source, lattice genes)
+    with _lib.Context(0) as ctx:
+        nbr = ctx.knn(coords, K)
+        ctx.graph_from_knn(1.0 / K)
+        ctx.set_expression(X, np.arange(G))
+        w = _lib.rng_state_words(np.random.default_rng(8))
+        out = ctx.moran_seeded(w, P)
+        par, seq, fallbacks, prepared, chained = ctx.permgen_stats()
+        assert (par, seq, fallbacks) == (1, 0, 0) and prepared > 5 * chained > 0
+        assert ctx.moran_source_bits() == 8 and ctx.moran_lag_bits() == 16
+        assert ctx.device_mem() < 150 * 2**30
+        wh = _lib.rng_state_words(np.random.default_rng(8))
+        last = None
+        for _ in range(10):                                        # the host generator in ten pieces of 100 x 5M (2 GB each)
+            last = _lib.perm_numpy_host(wh, n, P // 10)[-1].copy()
+        np.testing.assert_array_equal(w, wh)                      # state after P numpy permutations of 5M
+        np.testing.assert_array_equal(out["count_ge"], (out["sims"] >= out["I"]).sum(axis=0))
+        ctx.set_permutations(last[None, :])
+        np.testing.assert_array_equal(ctx.moran(1)["sims"][0], out["sims"][P - 1])
+        # two genes against the oracle: I (literal CSR sweep) and the last permutation's statistic (gather form)
+        cols = [0, 249]
+        g = csr_matrix((np.full(n * K, 1.0 / K), np.sort(nbr, axis=1).reshape(-1), np.arange(0, n * K + 1, K)), shape=(n, n))
+        vals = np.ascontiguousarray(X[:, cols].T, dtype=np.float64)
+        np.testing.assert_allclose(out["I"][cols], oracle.morans_i_scores(g, vals), rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(out["sims"][P - 1, cols], oracle.morans_i_sims_gather(g, vals, last[None, :])[0], rtol=1e-9, atol=1e-13)
+        assert np.abs(out["I"]).max() < 0.01                      # i.i.d. genes
+
+
+def test_config4_at_size_philox_enrichment_2048_permutations(big, oracle):
+    """BASELINE configs[4]'s 8-GPU form at size (r04): 1M cells, k = 30, 20 types, the COUNTER-BASED
+    label permutations (rng="philox": permutation p a pure function of (seed, p), so ranks take disjoint ranges of p and
+    add integer sums).  2048 permutations through the public function == the sums of two disjoint halves (what two ranks
+    would all-reduce), and the T x T tables of two single permutations against the oracle's restatement of the definition
+    (numpy Philox4x32-10 pinned by Random123's known answers, python-integer Lemire) -- the workgroup swap form at 1M."""
+    from conftest import make_adata
+    from spatialcore_amd.spatial import neighborhood_enrichment
+
+    ctx, coords, _ = big
+    T, P, k, seed = 20, 2048, 30, 99
+    codes = np.random.default_rng(3).choice(T, N, p=np.random.default_rng(4).dirichlet(np.ones(T))).astype(np.int32)
+    nbr = ctx.knn(coords, k)
+    ctx.graph_from_knn(1.0)
+    obs, sums = ctx.enrichment_counter(codes, T, seed, 0, P)
+    oa, sa = ctx.enrichment_counter(codes, T, seed, 0, P // 2)
+    ob, sb = ctx.enrichment_counter(codes, T, seed, P // 2, P // 2)
+    np.testing.assert_array_equal(obs, oa)
+    np.testing.assert_array_equal(obs, ob)
+    np.testing.assert_array_equal(sums, sa + sb)                 # two ranks' integer sums == one rank's
+    assert obs.sum() == N * k
+    indptr = np.arange(0, N * k + 1, k, dtype=np.int64)
+    cols = np.sort(nbr, axis=1).reshape(-1)
+    for p in (0, 1777):
+        _, one = ctx.enrichment_counter(codes, T, seed, p, 1)
+        perm = oracle.counter_permutation(seed, N, p)
+        want = oracle.enrichment_counts(indptr, cols, codes, T, perm[None, :])
+        np.testing.assert_array_equal(obs, want[1])
+        np.testing.assert_array_equal(obs + one[0], want[0])      # sums[0] = count - observed of that one permutation
+        np.testing.assert_array_equal(one[2], (want[0] >= want[1]).astype(np.int64))
+    labels = np.array([f"type{c:02d}" for c in range(T)])[codes]
+    ad = make_adata(coords, np.zeros((N, 1), dtype=np.float32), labels=labels)
+    neighborhood_enrichment(ad, "cell_type", k=k, n_permutations=P, seed=seed, rng="philox")
+    res = ad.uns["neighborhood_enrichment"]
+    np.testing.assert_array_equal(res["count"], obs)
+    np.testing.assert_array_equal(res["p_value"], (sums[2] + 1) / (P + 1))
+    np.testing.assert_allclose(res["mean"], obs + sums[0] / P, rtol=1e-12)
+    assert ad.uns["spatialcore_metadata"]["operations"][-1]["parameters"]["permgen_form"] == "counter-based (philox)"
