@@ -32,5 +32,6 @@ for k, nm in enumerate(names):
     tot += clk
     if cnt:
         print(f"computed blocks with {nm} steps left: {cnt / jobs:.2f} per permutation, {clk / cnt:.0f} clocks and {rounds / cnt:.1f} rounds each, {clk / jobs:.0f} clocks per permutation")
+print(f"units that waited > 20 us for their preparation: {int(prof[30])} of ~{jobs // 6} ({int(prof[19]) / jobs:.0f} clocks per permutation of the wait); longest wait {int(prof[31]) / 2.1e3:.0f} us")
 print(f"computed blocks in all {tot / jobs:.0f} clocks per permutation; waiting for a unit's preparation {int(prof[20]) / jobs:.0f}; "
       f"slow paths {int(prof[22]) / jobs:.2f} per permutation x {int(prof[21]) / max(int(prof[22]), 1):.0f} clocks; exposed table loads {int(prof[23]) / jobs:.2f} per permutation")

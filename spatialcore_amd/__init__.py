@@ -17,7 +17,7 @@ def init(device: int = 0) -> dict:
         # {'device': 0, 'hw_queues_requested': 24, 'streams_concurrent': True, 'generator': 'block-parallel'}
 
     ``streams_concurrent`` is MEASURED (a five-round stream probe, a few milliseconds); a ``False`` comes with a warning
-    on the ``spatialcore`` logger and ``generator`` = ``"sequential: <reason>"``.  Every drop-in function also records the
+    on the ``spatialcore_amd`` logger and ``generator`` = ``"sequential: <reason>"``.  Every drop-in function also records the
     form it ran with as ``permgen_form`` in its ``adata.uns["spatialcore_metadata"]`` entry.  Raises without a gfx950 GPU
     (there is no CPU fallback)."""
     from spatialcore_amd import _lib

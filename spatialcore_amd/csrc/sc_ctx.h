@@ -159,6 +159,7 @@ struct sc_ctx {
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
     DBuf pg_flags;       // hand-over words between the chain workgroup and the preparation launches (sc_permgen.hip)
     DBuf pg_desc, pg_tbits, pg_events, pg_hard;  // block-parallel scan: per-block descriptors + gap-transfer tables (ring), hard flags
+    DBuf pg_seglist;                             // ... per unit in flight: [count | first blocks of the segments k_phi_compose builds]
     DBuf pg_seg, pg_ctbits, pg_segmode;          // ... segments of prepared blocks: descriptors + composed tables (ring), per-block mode
 
     // ---- Moran / Lee work buffers ----

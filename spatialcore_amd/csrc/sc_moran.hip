@@ -1700,7 +1700,15 @@ static int64_t pipe_tail_total()
 static int pipe_generate(sc_ctx *c, PermPipe &pp, int64_t k)
 {
     hipEvent_t &scanned = pp.ev[(size_t)(2 * k)], &swapped = pp.ev[(size_t)(2 * k + 1)];
-    hipStream_t sw = (PIPE_SWAP_STREAMS > 1 && (k & 1)) ? c->stream4 : c->stream3;
+    // Two swap kernels in flight only for the job's LAST chunks (r04).  A swap workgroup is 8 wavefronts that live ~10 ms;
+    // two chunks' worth of them (256) spread over the ~96 CUs the scoring kernel leaves, next to the table builders' two-
+    // wavefront workgroups, left no CU with the 16 free wavefront slots a 1024-thread preparation workgroup needs: the
+    // chain's clock profile showed its units arriving 1-8 ms late behind every chunk boundary (55 k clocks of waiting per
+    // permutation; 37 k with one swap kernel at a time).  The tapering last chunks arrive 2-6 ms apart after the chain
+    // is all but done, and keep overlapping.
+    const int64_t chunks = (int64_t)pp.bounds.size() - 1;
+    const bool overlap = PIPE_SWAP_STREAMS > 1 && (k & 1) && (k >= chunks - 3 || getenv("SC_SWAP_OVERLAP_ALL") != nullptr);
+    hipStream_t sw = overlap ? c->stream4 : c->stream3;
     SC_HIP(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
     SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
     SC_TRY(permgen_scan_chunk(c, &pp.job, pp.bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
@@ -1728,7 +1736,8 @@ static void pipe_drain(sc_ctx *c, PermPipe &pp)
 
 // Begin: allocations, chunk schedule, the generator's set-up and its first `ahead` chunks (all of them when ahead
 // >= the number of chunks).  Needs nothing but n and the generator state -- no graph, no expression.
-static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, int table, PermPipe &pp, int64_t ahead)
+static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, int table, PermPipe &pp, int64_t ahead,
+                      const std::function<int()> &after_first_chunk = nullptr)
 {
     SC_REQUIRE(state6, SC_ERR_INVALID, "permutation pipeline: null generator state");
     SC_REQUIRE(n_perm >= 1, SC_ERR_INVALID, "permutation pipeline: n_perm must be >= 1");
@@ -1779,7 +1788,10 @@ static int pipe_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_pe
     for (int k = 0; k < 6; ++k) pp.state0[k] = state6[k];
     pp.job = PermJob();
     int rc = permgen_begin(c, state6, n, n_perm, &pp.job, c->stream2);
-    for (int64_t k = 0; k < chunks && k < ahead && rc == SC_OK; ++k) rc = pipe_generate(c, pp, k);
+    for (int64_t k = 0; k < chunks && k < ahead && rc == SC_OK; ++k) {
+        rc = pipe_generate(c, pp, k);
+        if (k == 0 && rc == SC_OK && after_first_chunk) rc = after_first_chunk();
+    }
     if (rc != SC_OK) pipe_drain(c, pp);
     return rc;
 }
@@ -1868,7 +1880,9 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
 }
 
 #ifndef SCORE_RESERVED_CUS
-#define SCORE_RESERVED_CUS 96
+#define SCORE_RESERVED_CUS 112   // r04 (two runs of 20 steps each, same box, ms per step): 96 -> 163.1 / 162.2, 112 -> 157.7 / 158.5,
+                                 // 128 -> 162.2 / 162.6, 144 -> 171.0 / 169.5; the scoring launches take the same 117 ms on 144 CUs
+                                 // as on 160 (13 rounds of tasks either way), the generator's preparation gets its CUs sooner
 #endif
 // SCORE_RESERVED_CUS: compute units the persistent scoring kernel leaves EMPTY for the generator that runs beside it.
 //
@@ -1937,6 +1951,10 @@ extern "C" int sc_moran_seeded_begin(sc_ctx *c, const uint64_t *state6, int64_t 
     // 0 = all of them (a caller with tens of milliseconds of host-blocking work in front of _finish: an upload), else at
     // least 2 (_finish enqueues the rest, two ahead of the scoring)
     const int64_t ahead_n = ahead_chunks <= 0 ? (int64_t)1 << 40 : (ahead_chunks < 2 ? 2 : ahead_chunks);
+    // (r04 measured again, and dropped again: the first half of the scoring's preparation enqueued right behind the
+    // generator's FIRST chunk for callers whose operands are resident -- scoring starts ~9 ms earlier, the step is 3.5 ms
+    // LONGER (165.4 vs 161.9 ms, same box): the full-chip column-sum kernels delay the generator's first units, and the
+    // scoring then only waits longer for its first chunks.)
     const int rc = pipe_begin(c, state6, n_cells, n_perm, permgen_can_swap_inverse(n_cells) ? 1 : 2, *pp, ahead_n);
     c->pg_ahead = ahead;
     if (rc != SC_OK) { delete pp; return rc; }

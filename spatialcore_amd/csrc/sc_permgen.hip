@@ -24,6 +24,7 @@
 //                   (those swaps commute), the rest is retried, so the result equals the sequential
 //                   shuffle bit for bit.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -273,7 +274,8 @@ __device__ __forceinline__ uint32_t expected_steps(uint32_t rem, float q, uint32
 }
 
 #ifdef PHI_PROFILE
-__device__ unsigned long long g_phi_prof[32];   // development: see k_chain, block_fixed_point (read by sc_permgen_profile)
+__device__ unsigned long long g_phi_prof[32 + 2 * 128];   // development: see k_chain, block_fixed_point (read by sc_permgen_profile);
+                                                          // [32 ..): log of (unit | first unit of the launch << 32, clocks waited) of long waits
 #endif
 
 struct BlockShared {
@@ -494,10 +496,16 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t *__restrict__ raw
                                   // threads: 80 -> 842, 112 -> 900, 160 -> 1017, 224 -> 1024, 320 -> 1020-1033 genes/s in
                                   // the pipeline; with 16-draw threads: 384 -> 1068, 448 -> 1067, 512 -> 1071)
 #endif
-#define PHI_AHEAD_MAX 3           // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
+#ifndef PHI_AHEAD_MAX
+#define PHI_AHEAD_MAX 3
+#endif
+                                  // units prepared ahead of the chain (their guesses use a state ahead + 1 units old):
                                   // 1 when the generator has the chip to itself, 3 next to the scoring kernel, whose
                                   // workgroups hold the CUs for milliseconds (wider windows, ~25 % more computed blocks)
-#define PHI_RING 4096             // table ring slots: EIGHT units.  Units are cut at chunk ends, so a short unit shifts the ring
+#ifndef PHI_RING
+#define PHI_RING 4096
+#endif
+                                // table ring slots: EIGHT units.  Units are cut at chunk ends, so a short unit shifts the ring
                                   // positions of its successors, and unit v + 5 can then land on slots of unit v.  The chain is
                                   // done with unit v by then (k_gate), but k_seg_fill(v) -- which runs behind the chain on stream
                                   // v % 4 -- need not be: with four units of slots, a fill starved of compute units for a
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
                                                              uint64_t b1, uint64_t ref_block,
                                                              const unsigned long long *__restrict__ sblk,
                                                              PhiDesc *__restrict__ desc,
-                                                             uint16_t *__restrict__ events)
+                                                             uint16_t *__restrict__ events, uint32_t *__restrict__ seglist)
 {
     __shared__ BlockShared sh;
     __shared__ unsigned long long shG;
@@ -632,6 +640,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
     const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
     const uint32_t M = n - 1, top_mask = mask_of(M);
     const uint64_t slot = b % PHI_RING;
+    if (blockIdx.x == 0 && tau == 0) seglist[0] = 0;   // the unit's list of multi-block segments (filled by k_phi_tbuild)
     if (tau == 0) {
         const double dq = (double)(b - ref_block) * (double)SCAN_BLOCK;
         shG = phi_expect(sblk[ref_block], dq, M, dpp, total_steps);
@@ -708,14 +717,81 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
     }
 }
 
+#ifndef PHI_SEG_MAX
+#define PHI_SEG_MAX 16        // blocks per segment at most (segments are cut at multiples of this inside a unit)
+#endif
+#define PHI_COMPOSE_WGS (PHI_UNIT / 2)   // workgroups of k_phi_compose: one per multi-block segment, the others leave at once
+#define PHI_NS 6              // segments whose tables the chain stages in LDS at once (a run of prepared blocks)
+#define PHI_STAGE_PIECES 64   // 16-byte pieces per side the chain stages: entry gaps up to 8192 (beyond: global memory)
+
+struct PhiSeg {               // one per ring slot, written by k_phi_compose
+    unsigned long long G;     // guessed entry state of the segment's first block
+    int32_t exit0;            // exit state of the segment for entry state G, relative to G
+    uint32_t i_in;            // steps left in G's permutation
+    uint16_t vpos, vneg;      // entry states G - vneg .. G + vpos are covered
+    uint8_t kind;             // 0: the chain computes this block itself, 1: first block of a segment, 2: inside one
+    uint8_t len;              // kind 1: blocks in the segment
+    uint8_t own;              // kind 1: the segment's table is the block's own (tbits), else the composed one (ctbits)
+    uint8_t bad;              // kind 1: the composition left the windows even for the base trajectory (never seen): no lookup
+};
+static_assert(sizeof(PhiSeg) == 24, "PhiSeg layout");
+
+__device__ __forceinline__ bool phi_full(const PhiDesc &d) { return d.prepared && d.w_pos == d.w && d.w_neg == d.w; }
+
+// set bits among the first nbit (1 .. 128) bits of a 16-byte piece (32-bit masks only, see xsl_rr32)
+__device__ __forceinline__ uint32_t phi_piece_rank(const ulonglong2 a, uint32_t nbit)
+{
+    const uint32_t wd[4] = {(uint32_t)a.x, (uint32_t)(a.x >> 32), (uint32_t)a.y, (uint32_t)(a.y >> 32)};
+    uint32_t T = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = 32u * j;
+        const uint32_t m = nbit >= lo + 32u ? 0xffffffffu : (nbit > lo ? ((1u << ((nbit - lo) & 31u)) - 1u) : 0u);
+        T += (uint32_t)__popc(wd[j] & m);
+    }
+    return T;
+}
+
+// Which segment a prepared block belongs to (r04, see "SEGMENTS" below): a function of the descriptors of the block, its
+// predecessor and its successors alone, so every block classifies ITSELF (thread 0 of its k_phi_tbuild workgroup) and the
+// first block of a segment of more than one block enters the unit's list for k_phi_compose.
+__device__ __forceinline__ void phi_classify(uint64_t b0, uint64_t b1, uint64_t b, const PhiDesc *__restrict__ desc,
+                                             PhiSeg *__restrict__ seg, uint32_t *__restrict__ seglist)
+{
+    const uint32_t r = (uint32_t)(b - b0), nb = (uint32_t)(b1 - b0);
+    const uint64_t slot = b % PHI_RING;
+    const PhiDesc cur = desc[slot];
+    PhiSeg s;
+    s.G = cur.G; s.exit0 = (int32_t)cur.cnt; s.i_in = cur.i_in; s.vpos = cur.w_pos; s.vneg = cur.w_neg;
+    s.kind = 0; s.len = 0; s.own = 1; s.bad = 0;
+    if (cur.prepared) {
+        bool start = r == 0 || (r % PHI_SEG_MAX) == 0 || !phi_full(cur);
+        if (!start) start = !phi_full(desc[(b - 1) % PHI_RING]);
+        if (!start) s.kind = 2;
+        else {
+            uint32_t len = 1;
+            if (phi_full(cur))
+                while (r + len < nb && ((r + len) % PHI_SEG_MAX) != 0 && phi_full(desc[(b + len) % PHI_RING])) ++len;
+            s.kind = 1; s.len = (uint8_t)len;
+            if (len > 1) {   // its table is composed by k_phi_compose (which completes this descriptor); until then: unusable
+                s.bad = 1;
+                seglist[1 + atomicAdd(seglist, 1u)] = r;
+            }
+        }
+    }
+    seg[slot] = s;
+}
+
 // Prepare blocks [b0, b1), part 2: two wavefronts per block turn the event lists into the gap-transfer tables.
 __global__ __launch_bounds__(128) void k_phi_tbuild(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
                                                     const uint16_t *__restrict__ events,
-                                                    unsigned long long *__restrict__ tbits)
+                                                    unsigned long long *__restrict__ tbits, PhiSeg *__restrict__ seg,
+                                                    uint32_t *__restrict__ seglist)
 {
     const uint64_t b = b0 + blockIdx.x;
     if (b >= b1) return;
     const uint64_t slot = b % PHI_RING;
+    if (threadIdx.x == 64) phi_classify(b0, b1, b, desc, seg, seglist);   // (the second wavefront's first lane; descriptors only)
     const PhiDesc d = desc[slot];
     if (!d.prepared) return;
     const uint32_t side = threadIdx.x >> 6;
@@ -850,8 +926,15 @@ int sc_permgen_profile(unsigned long long *out32, int reset)
 {
     SC_HIP(hipDeviceSynchronize());
     SC_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phi_prof), sizeof(unsigned long long) * 32));
+    if (getenv("SC_PHI_WAIT_LOG")) {   // development: the long waits of the chain, one line each
+        unsigned long long lg[2 * 128];
+        SC_HIP(hipMemcpyFromSymbol(lg, HIP_SYMBOL(g_phi_prof), sizeof(lg), sizeof(unsigned long long) * 32));
+        const unsigned long long cnt = out32[30] < 128 ? out32[30] : 128;
+        for (unsigned long long k = 0; k < cnt; ++k)
+            fprintf(stderr, "wait: unit %llu (launch began at unit %llu) %.0f us\n", lg[2 * k] & 0xffffffffull, lg[2 * k] >> 32, (double)lg[2 * k + 1] / 2100.0);
+    }
     if (reset) {
-        unsigned long long z[32] = {};
+        unsigned long long z[32 + 2 * 128] = {};
         SC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phi_prof), z, sizeof(z)));
     }
     return SC_OK;
@@ -876,43 +959,9 @@ int sc_permgen_profile(unsigned long long *out32, int) { memset(out32, 0, sizeof
 // of it exactly as before: the composed table of a segment is right or its last block's exit state does not meet the
 // chain's.
 // ------------------------------------------------------------------------------------------------
-#ifndef PHI_SEG_MAX
-#define PHI_SEG_MAX 16        // blocks per segment at most (segments are cut at multiples of this inside a unit)
-#endif
-#define PHI_NS 6              // segments whose tables the chain stages in LDS at once (a run of prepared blocks)
-#define PHI_STAGE_PIECES 64   // 16-byte pieces per side the chain stages: entry gaps up to 8192 (beyond: global memory)
-
-struct PhiSeg {               // one per ring slot, written by k_phi_compose
-    unsigned long long G;     // guessed entry state of the segment's first block
-    int32_t exit0;            // exit state of the segment for entry state G, relative to G
-    uint32_t i_in;            // steps left in G's permutation
-    uint16_t vpos, vneg;      // entry states G - vneg .. G + vpos are covered
-    uint8_t kind;             // 0: the chain computes this block itself, 1: first block of a segment, 2: inside one
-    uint8_t len;              // kind 1: blocks in the segment
-    uint8_t own;              // kind 1: the segment's table is the block's own (tbits), else the composed one (ctbits)
-    uint8_t bad;              // kind 1: the composition left the windows even for the base trajectory (never seen): no lookup
-};
-static_assert(sizeof(PhiSeg) == 24, "PhiSeg layout");
-
-__device__ __forceinline__ bool phi_full(const PhiDesc &d) { return d.prepared && d.w_pos == d.w && d.w_neg == d.w; }
-
-// set bits among the first nbit (1 .. 128) bits of a 16-byte piece (32-bit masks only, see xsl_rr32)
-__device__ __forceinline__ uint32_t phi_piece_rank(const ulonglong2 a, uint32_t nbit)
-{
-    const uint32_t wd[4] = {(uint32_t)a.x, (uint32_t)(a.x >> 32), (uint32_t)a.y, (uint32_t)(a.y >> 32)};
-    uint32_t T = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t lo = 32u * j;
-        const uint32_t m = nbit >= lo + 32u ? 0xffffffffu : (nbit > lo ? ((1u << ((nbit - lo) & 31u)) - 1u) : 0u);
-        T += (uint32_t)__popc(wd[j] & m);
-    }
-    return T;
-}
-
 // Prepare blocks [b0, b1), part 3: segments.  One workgroup per block; the workgroup of a segment's first block
 // composes the segment's table, the others only classify their block.
-__device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+__device__ __forceinline__ void phi_compose_block(uint64_t b0, uint32_t r, const PhiDesc *__restrict__ desc,
                                                   const unsigned long long *__restrict__ tbits, PhiSeg *__restrict__ seg,
                                                   unsigned long long *__restrict__ ctbits)
 {
@@ -922,23 +971,13 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
     __shared__ uint32_t wtot[4];            // set bits of pieces 0 .. 63 / 64 .. 127 of each side
     __shared__ uint32_t Uw[2 * PHI_W / 32]; // the block's increments on the signed gap axis: bit PHI_W + d = F(d + 1) - F(d)
     __shared__ int32_t shLoT, shHiT, shE0;  // first thread of each side that dropped out; exit state of the base
-    const uint64_t b = b0 + blockIdx.x;
-    if (b >= b1) return;
-    const uint32_t r = blockIdx.x, nb = (uint32_t)(b1 - b0), tau = threadIdx.x;
+    const uint64_t b = b0 + r;
+    const uint32_t tau = threadIdx.x;
     const uint64_t slot = b % PHI_RING;
     const PhiDesc cur = desc[slot];
-    PhiSeg s;
-    s.G = cur.G; s.exit0 = (int32_t)cur.cnt; s.i_in = cur.i_in; s.vpos = cur.w_pos; s.vneg = cur.w_neg;
-    s.kind = 0; s.len = 0; s.own = 1; s.bad = 0;
-    if (!cur.prepared) { if (tau == 0) seg[slot] = s; return; }
-    bool start = r == 0 || (r % PHI_SEG_MAX) == 0 || !phi_full(cur);
-    if (!start) { const PhiDesc prev = desc[(b - 1) % PHI_RING]; start = !phi_full(prev); }
-    if (!start) { s.kind = 2; if (tau == 0) seg[slot] = s; return; }
-    uint32_t len = 1;
-    if (phi_full(cur))
-        while (r + len < nb && ((r + len) % PHI_SEG_MAX) != 0 && phi_full(desc[(b + len) % PHI_RING])) ++len;
-    s.kind = 1; s.len = (uint8_t)len;
-    if (len == 1) { if (tau == 0) seg[slot] = s; return; }   // its own table serves
+    PhiSeg s = seg[slot];                   // kind 1, len > 1 (phi_classify)
+    const uint32_t len = s.len;
+    __syncthreads();                        // (the shared cells below are reused from the workgroup's previous segment)
 
     // ---- compose: every entry state of the window through the segment's tables ----
     // Thread (side, t) owns the 33 entry gaps 32 t .. 32 t + 32 of its side, held ASCENDING on the signed state axis
@@ -954,12 +993,20 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
     bool ok = true;
     if (tau == 0) { shLoT = 512; shHiT = 512; }
     const ulonglong2 *tb2 = reinterpret_cast<const ulonglong2 *>(tbits);
+    // the tables and the descriptor of block j + 1 are on their way (registers) while block j is applied: a step is
+    // then its ~360 instructions per thread, not those plus two dependent trips to memory (inside the Moran pipeline,
+    // next to 6 TB/s of scoring traffic, such a trip takes several microseconds)
+    ulonglong2 vnext = make_ulonglong2(0ull, 0ull);
+    unsigned long long nG = cur.G;      // (only the three fields a step needs travel ahead: the whole descriptor spilled)
+    uint32_t ncnt = cur.cnt, nw = cur.w;
+    if (tau < 256) vnext = tb2[((slot * 2 + (tau >> 7)) * PHI_WORDS) / 2 + (tau & 127u)];
     for (uint32_t j = 0; j < len; ++j) {
-        const PhiDesc dj = desc[(b + j) % PHI_RING];
+        const unsigned long long djG = nG;
+        const uint32_t djcnt = ncnt, djw = nw;
+        const ulonglong2 v = vnext;
         __syncthreads();     // the previous block's lookups are done (and shLoT / shHiT are set)
         if (tau < 256) {     // piece (tau & 127) of side (tau >> 7); a wavefront's 64 pieces are half a side
             const uint32_t piece = tau & 127u;
-            const ulonglong2 v = tb2[((((b + j) % PHI_RING) * 2 + (tau >> 7)) * PHI_WORDS) / 2 + piece];
             const uint32_t ones = (uint32_t)(__popcll(v.x) + __popcll(v.y));
             const uint32_t upto = wave_inclusive_scan(ones);
             tl[tau] = v;
@@ -974,9 +1021,14 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
                 for (int m = 0; m < 4; ++m) Uw[PHI_W / 32 - 4 * piece - 1 - m] = __brev(wd[m]);
             }
         }
+        if (j + 1 < len) {
+            const uint64_t sn = (b + j + 1) % PHI_RING;
+            nG = desc[sn].G; ncnt = desc[sn].cnt; nw = desc[sn].w;
+            if (tau < 256) vnext = tb2[((sn * 2 + (tau >> 7)) * PHI_WORDS) / 2 + (tau & 127u)];
+        }
         __syncthreads();
-        const int32_t rel = (int32_t)(int64_t)(dj.G - cur.G);   // this block's guess, relative to the first one's
-        const int32_t wj = (int32_t)dj.w;
+        const int32_t rel = (int32_t)(int64_t)(djG - cur.G);   // this block's guess, relative to the first one's
+        const int32_t wj = (int32_t)djw;
         if (ok && (st[0] - rel < -wj || st[32] - rel > wj)) {   // (also: gaps beyond the first block's own window)
             ok = false;
             atomicMin(side ? &shLoT : &shHiT, (int32_t)t);
@@ -991,7 +1043,7 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
                 const uint32_t row = (neg ? 128u : 0u) + piece;
                 T = tpre[row] + (piece >= 64u ? wtot[neg ? 2 : 0] : 0u) + phi_piece_rank(tl[row], nbit);
             }
-            int32_t run = rel + (int32_t)dj.cnt + (neg ? -(int32_t)T : (int32_t)T);
+            int32_t run = rel + (int32_t)djcnt + (neg ? -(int32_t)T : (int32_t)T);
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int32_t inc = st[k + 1] - st[k];                       // 0 or 1
@@ -1016,6 +1068,7 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
     if (tau == 0) {
         const int32_t hiT = shHiT, loT = shLoT, e0 = shE0;
         s.own = 0;
+        s.bad = 0;
         if (e0 == (int32_t)0x80000000 || hiT == 0 || loT == 0) { s.bad = 1; s.vpos = 0; s.vneg = 0; }
         else {
             const uint32_t vp = 32u * (uint32_t)hiT, vn = 32u * (uint32_t)loT;
@@ -1029,13 +1082,19 @@ __device__ __forceinline__ void phi_compose_block(uint64_t b0, uint64_t b1, cons
 
 // (r04 measured and dropped: the unit published by the LAST workgroup of this kernel -- a device-scope release per
 // workgroup, i.e. a write-back of the XCD's L2 512 times per unit: generator alone 119 -> 144 ms, bench step 167 -> 214 ms.
-// The kernel boundary in front of k_publish does that once.)
-__global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, uint64_t b1, const PhiDesc *__restrict__ desc,
+// The kernel boundary in front of k_publish does that once.  Also measured: one 1024-thread workgroup per BLOCK, all but
+// the ~35 that start a multi-block segment leaving at once -- inside the Moran pipeline those 512 heavy workgroups queued
+// for the 96 free CUs, the chain waited 34-40 k clocks per permutation for its units (3.4 k with the chip to itself).)
+__global__ __launch_bounds__(SCAN_THREADS) void k_phi_compose(uint64_t b0, const PhiDesc *__restrict__ desc,
                                                              const unsigned long long *__restrict__ tbits,
                                                              PhiSeg *__restrict__ seg,
-                                                             unsigned long long *__restrict__ ctbits)
+                                                             unsigned long long *__restrict__ ctbits,
+                                                             const uint32_t *__restrict__ seglist)
 {
-    phi_compose_block(b0, b1, desc, tbits, seg, ctbits);
+    const uint32_t count = seglist[0];
+    // (one segment per workgroup -- a segment has at least two blocks, so PHI_UNIT / 2 workgroups cover any unit; a loop
+    // over segments here made hipcc spill 25 registers of the unrolled state arrays)
+    if (blockIdx.x < count) phi_compose_block(b0, seglist[1 + blockIdx.x], desc, tbits, seg, ctbits);
 }
 
 // Entry states of the blocks inside the segments of blocks [b0, b1) that the chain resolved by ONE lookup (segmode 1):
@@ -1127,7 +1186,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     if (tau == 0) shReady = (uint32_t)phi_wait_at_least(flags + 1 + unit % PHI_FLAG_SLOTS, unit + 1, st);
     __syncthreads();
 #ifdef PHI_PROFILE
-    if (tau == 0) atomicAdd(&g_phi_prof[20], (unsigned long long)(clock64() - pf_w0));   // waiting for the unit's preparation
+    if (tau == 0) {   // waiting for the unit's preparation: total, units that waited > 20 us, longest wait
+        const unsigned long long wt = (unsigned long long)(clock64() - pf_w0);
+        atomicAdd(&g_phi_prof[20], wt);
+        if (wt > 40000ull) {
+            const unsigned long long k = atomicAdd(&g_phi_prof[30], 1ull);
+            atomicAdd(&g_phi_prof[19], wt);
+            if (k < 128) { g_phi_prof[32 + 2 * k] = (unsigned long long)unit | ((unsigned long long)unit0 << 32); g_phi_prof[33 + 2 * k] = wt; }
+        }
+        atomicMax(&g_phi_prof[31], wt);
+    }
 #endif
     if (shReady) { gave_up = (int)shReady; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the unit's descriptors and tables, written by other kernels
@@ -1602,6 +1670,7 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         SC_TRY(c->pg_seg.ensure(sizeof(PhiSeg) * (size_t)PHI_RING, &c->mem));
         SC_TRY(c->pg_ctbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
         SC_TRY(c->pg_segmode.ensure((size_t)n_blocks + 1, &c->mem));
+        SC_TRY(c->pg_seglist.ensure(sizeof(uint32_t) * (size_t)PHI_FLAG_SLOTS * (1 + PHI_UNIT), &c->mem));
         SC_HIP(hipMemsetAsync(c->pg_segmode.p, 0, (size_t)n_blocks + 1, s));
         int prio_lo = 0, prio_hi = 0;  // the generator is the critical path of its callers (plain streams if refused)
         const bool prio = getenv("SC_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
@@ -1668,6 +1737,12 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
         // (k_chain raises a flag if they do not complete the chunk); the last chunk takes all blocks.
         const double need = (double)p1 * job->draws_per_perm + 9000.0 * sqrt((double)p1) + (double)SCAN_BLOCK;
         uint64_t B_end = (uint64_t)(need / SCAN_BLOCK) + 1;
+        // ... rounded UP to whole launch units (r04).  A chunk that ends inside a unit leaves a SHORT last unit, which the
+        // chain finishes in a fraction of a unit's time -- and the first unit of the next chunk, prepared `ahead` units ahead
+        // in chain time, is then not ready: the clock profile of the chain inside the Moran pipeline showed ~13 such waits
+        // per 1000 x 1M job, 1-2 ms each (20 of the chain's 130 ms), and nothing in between.  The extra blocks (< 6
+        // permutations' worth) are simply scanned one chunk earlier.
+        B_end = (B_end + PHI_UNIT - 1) / PHI_UNIT * PHI_UNIT;
         if (B_end > n_blocks || p1 >= job->n_perm) B_end = n_blocks;
         phi_first = job->B_done;
         phi_end = B_end;
@@ -1685,6 +1760,7 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             // The guess of unit u uses the exact state at the start of unit u - ahead, which the chain leaves when it
             // completes unit u - ahead - 1; that unit also is the last reader of the ring slots unit u overwrites.
             const int64_t dep = u - job->ahead - 1;
+            uint32_t *seglist = c->pg_seglist.as<uint32_t>() + (size_t)(u % PHI_FLAG_SLOTS) * (1 + PHI_UNIT);
             const uint64_t ref = u >= job->ahead ? job->unit_start[(size_t)((u - job->ahead) % 8)] : 0;
             if (u < PHI_STREAMS) SC_HIP(hipStreamWaitEvent(sp, c->pg_ev[32], 0));  // the raw stream (recorded by permgen_begin)
             // (a gate in front of this stream's last k_seg_fill has waited for the same or a later "unit done" already)
@@ -1693,13 +1769,13 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             hipLaunchKernelGGL(k_phi_events, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp,
                                c->pg_raw.as<uint32_t>(), (uint32_t)job->n, job->total_steps, job->draws_per_perm, b0,
                                b1, ref, c->pg_sblk.as<unsigned long long>(), c->pg_desc.as<PhiDesc>(),
-                               c->pg_events.as<uint16_t>());
+                               c->pg_events.as<uint16_t>(), seglist);
             hipLaunchKernelGGL(k_phi_tbuild, dim3((unsigned)(b1 - b0)), dim3(128), 0, sp, b0, b1,
                                c->pg_desc.as<PhiDesc>(), c->pg_events.as<uint16_t>(),
-                               c->pg_tbits.as<unsigned long long>());
-            hipLaunchKernelGGL(k_phi_compose, dim3((unsigned)(b1 - b0)), dim3(SCAN_THREADS), 0, sp, b0, b1,
+                               c->pg_tbits.as<unsigned long long>(), c->pg_seg.as<PhiSeg>(), seglist);
+            hipLaunchKernelGGL(k_phi_compose, dim3(PHI_COMPOSE_WGS), dim3(SCAN_THREADS), 0, sp, b0,
                                c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(), c->pg_seg.as<PhiSeg>(),
-                               c->pg_ctbits.as<unsigned long long>());
+                               c->pg_ctbits.as<unsigned long long>(), seglist);
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sp, flags, (uint32_t)(1 + u % PHI_FLAG_SLOTS), (uint32_t)(u + 1));
             // behind the chain's "unit u done": the entry states of the blocks inside the unit's segments (this stream's
             // next unit, u + PHI_STREAMS, overwrites the ring slots they are read from and is enqueued behind this)

@@ -240,7 +240,7 @@ import numpy as np
 import spatialcore_amd
 from spatialcore_amd import _lib
 buf = io.StringIO()
-logging.getLogger("spatialcore").addHandler(logging.StreamHandler(buf))
+logging.getLogger("spatialcore_amd").addHandler(logging.StreamHandler(buf))
 rep = spatialcore_amd.init()
 print("REPORT", rep["hw_queues_requested"], int(rep["streams_concurrent"]), rep["generator"].replace("\n", " "), flush=True)
 from conftest import make_adata, synth
