@@ -294,6 +294,7 @@ def main() -> None:
 
     gathered = None
     mem_peak = 0
+    batch_walls = []     # (batch index, wall seconds) of every batch call: strong mode reports the generator's share
 
     import contextlib
 
@@ -323,12 +324,14 @@ def main() -> None:
         rows = []
         res = None
         for bi, (b0, b1) in enumerate(batches):
+            tb = time.perf_counter()
             if len(batches) > 1:
                 ctx.set_expression(batch_matrix(bi)[:, : b1 - b0], np.arange(b1 - b0))   # upload inside the step
             if bi == 0:
                 res = _moran_resident(ctx, n, P, args.seed, begun=begun)   # generator + scoring, pipelined
             else:
                 res = _moran_resident(ctx, n, P, args.seed, reuse_table=True)   # the rank's resident table
+            batch_walls.append((bi, time.perf_counter() - tb))   # (every call ends with a stream synchronisation)
             rows.append(np.stack([res["I"], res["p_value"]], axis=1))
         mem_peak = max(mem_peak, ctx.device_mem())
         mine = np.concatenate(rows, axis=0) if rows else np.zeros((0, 2))
@@ -343,6 +346,7 @@ def main() -> None:
     fence()
     ctx.reset_timers()
     pg0 = ctx.permgen_stats()
+    batch_walls.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -497,6 +501,27 @@ def main() -> None:
             if bits_alt in other_sources:
                 line[f"value_{name}_source"] = other_sources[bits_alt]["value"]
                 line[f"{name}_source"] = other_sources[bits_alt]
+        if strong:
+            # Every rank regenerates the FULL permutation table (it depends on the seed and n alone), pipelined with the
+            # scoring of its first gene batch; the later batches score against the resident table.  A rank's step is
+            # therefore first_batch + (its batches - 1) x later_batch, and only the second term shrinks with more ranks.
+            first = [w for bi, w in batch_walls if bi == 0]
+            later = [w for bi, w in batch_walls if bi > 0]
+            first_ms = 1e3 * sum(first) / max(len(first), 1)
+            later_ms = 1e3 * sum(later) / max(len(later), 1) if later else None
+            per = later_ms if later_ms is not None else first_ms
+
+            def model(nr):
+                nb = -(-(-(-genes_arg // nr)) // batch)      # batches of the largest shard
+                return first_ms + (nb - 1) * per
+            line["strong_scaling"] = {
+                "first_batch_ms": first_ms, "later_batch_ms": later_ms, "batches_this_rank": len(batches), "gene_batch": batch,
+                "generator_kernels_ms_per_step": scan_ms / args.steps, "scoring_kernels_ms_per_step": perm_ms / args.steps,
+                "model": "t(N) = first_batch_ms + (batches of the largest shard - 1) x later_batch_ms; the first batch holds the "
+                         "whole generator job (every rank regenerates the full table), so it does not shrink with N",
+                "model_ms": {str(nr): model(nr) for nr in (1, 2, 4, 8)},
+                "implied_speedup_8_over_1": model(1) / model(8),
+                "status": "unmeasured on hardware for N > 1: a bound from this rank's own per-batch times"}
         if fallbacks:
             line["warning"] = "the block-parallel generator fell back to the sequential scan inside the timed region"
         if world == 1 and not strong and not args.no_public_api:

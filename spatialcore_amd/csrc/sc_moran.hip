@@ -375,6 +375,50 @@ __global__ __launch_bounds__(256) void k_lag(const int64_t *__restrict__ indptr,
     Lt[i * 8 + q] = make_double2(sx, sy);
 }
 
+// The same lag from the float32 narrow rows (r04): a float32-source batch has its raw values as 32 genes per 128-byte row
+// (k_pack_narrow<32>: the lane's 16 bytes = genes {16 t + 2 q, + 1} of the group's two tiles), so a neighbour costs one
+// 16-byte piece per lane for FOUR genes instead of one per tile for two -- half the gathered bytes (what bounds k_lag is
+// the rows through the CUs' vector memory path, section 4.2 of DESIGN.md).  z = (double)x - centre is rebuilt in
+// registers, the very value the Z tile holds; products and sums rounded separately, edges in ascending order: Lag is
+// k_lag's bit for bit.
+__global__ __launch_bounds__(256) void k_lag_f32rows(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                     const double *__restrict__ w, const uint4 *__restrict__ narrow,
+                                                     const double *__restrict__ centre, double *__restrict__ Lag, int64_t n,
+                                                     int tiles16, const double *__restrict__ unit,
+                                                     const int32_t *__restrict__ order)
+{
+    const int64_t per_xcd = (int64_t)(gridDim.x >> 3);                 // gridDim.x is a multiple of 8
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t t = blk * blockDim.x + threadIdx.x;
+    const int64_t pos = t >> 3;
+    const int q = (int)(t & 7);
+    if (pos >= n) return;
+    const int64_t i = order ? order[pos] : pos;
+    const int grp = blockIdx.y;                                        // 32 genes = tiles 2 grp, 2 grp + 1
+    const int tiles_left = tiles16 - 2 * grp;
+    const uint4 *Xg = narrow + (int64_t)grp * n * 8;
+    double cen[4];
+    bool un[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t g = (int64_t)(2 * grp + ((k >> 1) < tiles_left ? (k >> 1) : 0)) * SC_TILE + 2 * q + (k & 1);
+        cen[k] = centre[g];
+        un[k] = unit && unit[g] != 0.0;
+    }
+    const int64_t e0 = indptr[i], e1 = indptr[i + 1];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t e = e0; e < e1; ++e) {
+        const uint4 v = Xg[(int64_t)indices[e] * 8 + q];
+        const double ww = w[e];
+        const double z[4] = {(double)__uint_as_float(v.x) - cen[0], (double)__uint_as_float(v.y) - cen[1],
+                             (double)__uint_as_float(v.z) - cen[2], (double)__uint_as_float(v.w) - cen[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = __dadd_rn(s[k], __dmul_rn(un[k] ? 1.0 : ww, z[k]));
+    }
+    reinterpret_cast<double2 *>(Lag + (int64_t)(2 * grp) * n * SC_TILE)[i * 8 + q] = make_double2(s[0], s[1]);
+    if (tiles_left > 1) reinterpret_cast<double2 *>(Lag + (int64_t)(2 * grp + 1) * n * SC_TILE)[i * 8 + q] = make_double2(s[2], s[3]);
+}
+
 static int launch_lag(sc_ctx *c, const DBuf &indptr, const DBuf &indices, const DBuf &data, const double *Z,
                       double *out, const double *unit = nullptr)
 {
@@ -726,6 +770,9 @@ __global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict
 // ------------------------------------------------------------------------------------------------
 
 #define SCORE_WAVES 16
+#define SCORE_PRIVATE_WAVES 8   // k_moran_score (r04): 512-thread workgroups -- under the 128-VGPR cap of a 1024-thread workgroup
+                                // its private lag staging spilled 6-10 registers (28-44 B of scratch per lane); its wavefronts
+                                // are independent workers, so two workgroups of 8 per compute unit are the same 16 workers
 
 // L16 (BITS == 8 only, r04): the lag operand arrives as the 16-bit neighbour sums k_lag_u8 leaves -- Lag16[group][cell][t][q]
 // = S of genes (16 t + 2 q, + 1) as two uint16 in one word, 256 bytes per cell and 128-gene group instead of 1 KB of fp64
@@ -733,7 +780,7 @@ __global__ __launch_bounds__(256) void k_check_inverse(const int32_t *__restrict
 __device__ __forceinline__ double2 lag16_to_double2(uint32_t v) { return make_double2((double)(v & 0xffffu), (double)(v >> 16)); }
 
 template <int BITS, int CB, bool BIG, bool L16 = false>
-__global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
+__global__ __launch_bounds__(SCORE_PRIVATE_WAVES * 64) void k_moran_score(
     const uint4 *__restrict__ narrow, const double *__restrict__ Lag, int64_t tile_elems, int tiles16,
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
     int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
@@ -750,7 +797,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     constexpr int NI = CB / 4;                   // index vectors per block
     constexpr int NL = CB * ROW / 64;            // lag pieces per lane and block
     constexpr int CSTEP = 64 / ROW;              // cells covered by one cooperative lag load
-    __shared__ double2 lds_lag[SCORE_WAVES][2][CB * ROW];   // [wavefront][buffer][cell][ROW]
+    __shared__ double2 lds_lag[SCORE_PRIVATE_WAVES][2][CB * ROW];   // [wavefront][buffer][cell][ROW]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane >> 3, q = lane & 7;
     const int lcell0 = lane / ROW, ltile = (lane % ROW) >> 3;
@@ -759,7 +806,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score(
     // (Measured and dropped in r02: giving each XCD -- blockIdx % 8 -- its own subset of the cell splits, so that a
     //  split's lag rows are fetched by one L2 only: same launch time, same PMC traffic.)
     const int64_t n_tasks = (int64_t)n_groups * n_splits * pgroups;
-    const int64_t worker = (int64_t)blockIdx.x * SCORE_WAVES + wave, workers = (int64_t)gridDim.x * SCORE_WAVES;
+    const int64_t worker = (int64_t)blockIdx.x * SCORE_PRIVATE_WAVES + wave, workers = (int64_t)gridDim.x * SCORE_PRIVATE_WAVES;
 
     for (int64_t task = worker; task < n_tasks; task += workers) {
         const int pg = (int)(task % pgroups);
@@ -1375,6 +1422,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     // ... with the neighbour sums kept as the 16-bit integers they are (r04): a quarter of the bytes k_lag_u8 writes in the
     // serial prelude and of the lag bytes every scoring launch streams (SC_LAG_FP64: the r03 form, for A/B runs)
     const bool lag16 = u8_prelude && !getenv("SC_LAG_FP64");
+    bool narrow_packed = false;   // the narrow copy of the batch exists already (built in front of the lag that reads it)
     c->lag_u16 = lag16;
     if (u8_prelude) {
         c->lm_valid = false;   // (Lag is about to be rewritten)
@@ -1398,6 +1446,20 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
         SC_HIP(hipGetLastError());
     } else {
         SC_TRY(expr_write_z(c, c->g_meanc.as<double>()));
+        const bool lag_from_rows = n_perm > 0 && bits == 32 && !getenv("SC_LAG_FP64_ROWS");   // (SC_LAG_FP64_ROWS: the r03 form, A/B)
+        if (lag_from_rows) {   // the float32 narrow copy first, then the lag from ITS rows (half the gathered bytes of the fp64 tiles)
+            SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
+            hipLaunchKernelGGL(k_pack_narrow<32>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, 2)), dim3(256), 0,
+                               c->stream, c->X.as<double>(), c->X32.as<uint4>(), n, T);
+            const int32_t *order = (c->g_order_captured && c->g_n == n && c->g_order.p) ? c->g_order.as<int32_t>() : nullptr;
+            KernelTimerScope ts(c, SC_K_LAG);
+            hipLaunchKernelGGL(k_lag_f32rows, dim3((unsigned)align_up64(ceil_div64(n * 8, 256), 8), (unsigned)ceil_div64(T, 2)),
+                               dim3(256), 0, c->stream, c->g_indptr.as<int64_t>(), c->g_indices.as<int32_t>(),
+                               c->g_data.as<double>(), c->X32.as<uint4>(), c->g_meanc.as<double>(), c->Lag.as<double>(), n, (int)T,
+                               lat_any ? c->g_lat.as<double>() : nullptr, order);
+            SC_HIP(hipGetLastError());
+            narrow_packed = true;
+        } else
         SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>(),
                           lat_any ? c->g_lat.as<double>() : nullptr));
         SC_TRY(colsum<OP_MUL>(c, c->Z.as<double>(), c->Lag.as<double>(), c->g_Inum.as<double>(), 1.0));
@@ -1418,7 +1480,7 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
         const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
         const size_t wide_rows = (size_t)splits64 * SC_TILE;
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
-        if (bits < 64 && !u8_prelude) {
+        if (bits < 64 && !u8_prelude && !narrow_packed) {
             // the gathered operand: the raw values in the narrowest type that holds every gene of the batch exactly
             const int64_t T32 = (T + 1) / 2;
             SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= the uint16 / uint8 copies
@@ -1508,7 +1570,8 @@ static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int 
                            splits, groups);
         return;
     }
-    hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG, L16>), dim3((unsigned)wgs), dim3(SCORE_WAVES * 64), 0, c->stream, rows,
+    hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG, L16>), dim3((unsigned)(wgs * (SCORE_WAVES / SCORE_PRIVATE_WAVES))),
+                       dim3(SCORE_PRIVATE_WAVES * 64), 0, c->stream, rows,
                        c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
                        c->inv.as<int32_t>() + p0 * c->p_stride, c->partial.as<double>(), c->e_n, c->p_stride, cnt, cps,
                        splits, groups);
