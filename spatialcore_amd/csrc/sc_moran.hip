@@ -1708,6 +1708,12 @@ extern "C" int sc_moran(sc_ctx *c, int64_t n_perm, double *I_out, double *sims_o
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
+// (what the number means and how it was chosen: the comment in front of moran_seeded_streams)
+#ifndef SCORE_RESERVED_CUS
+#define SCORE_RESERVED_CUS 112   // r04 (two runs of 20 steps each, same box, ms per step): 96 -> 163.1 / 162.2, 112 -> 157.7 / 158.5,
+                                 // 128 -> 162.2 / 162.6, 144 -> 171.0 / 169.5; the scoring launches take the same 117 ms on 144 CUs
+                                 // as on 160 (13 rounds of tasks either way), the generator's preparation gets its CUs sooner
+#endif
 #ifndef PIPE_AHEAD
 #define PIPE_AHEAD 3         // launch units the generator's preparation runs ahead of its chain inside the pipeline
 #endif
@@ -1919,6 +1925,10 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     auto prepare = [&]() -> int {
         SC_TRY(moran_prepare(c, n_perm < PERM_CHUNK ? n_perm : PERM_CHUNK, true));
         bits = c->narrow_bits;
+        // CUs left to the generator, by source width (r04, bench size, ms per step at 64 / 80 / 96 / 112 CUs left): the uint8
+        // step is balanced between generator and scoring (SCORE_RESERVED_CUS); uint16 243.0 / 246.8 / 238.5 / 239.2; float32,
+        // whose step is scoring-bound, 389.3 / 390.4 / 398.1 / 408.6
+        if (c->score_leave_cus > 8 && !getenv("SC_SCORE_LEAVE_CUS")) c->score_leave_cus = bits == 8 ? SCORE_RESERVED_CUS : bits == 16 ? 96 : 64;
         return SC_OK;
     };
     auto score = [&](int64_t p0, int64_t p1) -> int {
@@ -1930,8 +1940,10 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
         if (keep > 8) {
             int tail_prev = keep < 32 ? keep : 32, tail_last = 8;
             if (const char *v = getenv("SC_SCORE_LEAVE_TAIL")) sscanf(v, "%d,%d", &tail_prev, &tail_last);
+            int64_t tail_from = pipe_tail_total();   // launches with fewer permutations than this still to come use tail_prev
+            if (const char *v = getenv("SC_SCORE_TAIL_PERMS")) tail_from = atoi(v);   // development: sweep
             if (p1 == n_perm) c->score_leave_cus = tail_last;
-            else if (n_perm > 3 * PERM_CHUNK && n_perm - p1 < pipe_tail_total()) c->score_leave_cus = tail_prev;
+            else if (n_perm > 3 * PERM_CHUNK && n_perm - p1 < tail_from) c->score_leave_cus = tail_prev;
         }
         const int rc = moran_perm_range(c, p0, p1, bits, false);
         c->score_leave_cus = keep;
@@ -1942,11 +1954,6 @@ static int moran_seeded_once(sc_ctx *c, uint64_t *state6, int64_t n_perm, double
     return moran_finish(c, n_perm, I_out, sims_out, count_ge_out, sim_sum_out, sim_sumsq_out);
 }
 
-#ifndef SCORE_RESERVED_CUS
-#define SCORE_RESERVED_CUS 112   // r04 (two runs of 20 steps each, same box, ms per step): 96 -> 163.1 / 162.2, 112 -> 157.7 / 158.5,
-                                 // 128 -> 162.2 / 162.6, 144 -> 171.0 / 169.5; the scoring launches take the same 117 ms on 144 CUs
-                                 // as on 160 (13 rounds of tasks either way), the generator's preparation gets its CUs sooner
-#endif
 // SCORE_RESERVED_CUS: compute units the persistent scoring kernel leaves EMPTY for the generator that runs beside it.
 //
 // The scoring kernel would fill every compute unit with wavefronts that live for milliseconds, and the generator is

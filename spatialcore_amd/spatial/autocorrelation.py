@@ -262,7 +262,11 @@ def _moran_resident(ctx, n_cells: int, n_permutations: int, seed: int, reuse_tab
     if n_permutations > 0 and reuse_table:
         out = ctx.moran(n_permutations, return_sims=False)
     elif n_permutations > 0 and begun is not None:
-        ctx.graph_moments()      # (needs the transposed graph: built here, beside the generator, not after the scoring)
+        # the graph moments (transpose + reverse-edge search on the side stream) are collected HERE, a host wait of a few
+        # milliseconds in front of the scoring's set-up.  r04 measured the set-up without it (it starts the moments itself):
+        # the scoring began ~4 ms earlier and the step was 4 ms LONGER (161.6 / 162.5 vs 158.0 / 157.2 ms, same box) -- like
+        # every other attempt to pull the scoring's full-chip prelude kernels forward into the generator's first units.
+        ctx.graph_moments()
         out = ctx.moran_seeded_finish(begun, return_sims=False)
     elif n_permutations > 0:
         # squidpy: default_rng(seed + chunk index), one chunk when n_jobs=1.  Table generation and
