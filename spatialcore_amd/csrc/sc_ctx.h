@@ -69,6 +69,7 @@ struct sc_ctx {
     hipStream_t stream4 = nullptr;  // ... alternating with this one
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
     hipStream_t stream_px = nullptr;     // ... and verifies + expands a finished chunk here, beside the next chunk's chain
+    hipStream_t stream_fr = nullptr;     // ... and the fresh-table helpers of a chain launch live here (k_fresh)
     hipEvent_t pg_ev[34] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
     bool pg_streams_serial = false;   // a wait on a hand-over word gave up once: the streams of this process do not run
@@ -159,6 +160,7 @@ struct sc_ctx {
     DBuf pg_J, pg_raw, pg_out, pg_bits, pg_enter, pg_sblk;  // device generator scratch: accepted j per step, raw 32-bit stream
     DBuf pg_flags;       // hand-over words between the chain workgroup and the preparation launches (sc_permgen.hip)
     DBuf pg_desc, pg_tbits, pg_events, pg_hard;  // block-parallel scan: per-block descriptors + gap-transfer tables (ring), hard flags
+    DBuf pg_fresh;                               // ... fresh tables for the ends of the permutations: control block, descriptors, tables
     DBuf pg_seglist;                             // ... per unit in flight: [count | first blocks of the segments k_phi_compose builds]
     DBuf pg_seg, pg_ctbits, pg_segmode;          // ... segments of prepared blocks: descriptors + composed tables (ring), per-block mode
 

@@ -1795,6 +1795,7 @@ static void pipe_drain(sc_ctx *c, PermPipe &pp)
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     if (c->stream_px) (void)hipStreamSynchronize(c->stream_px);
+    if (c->stream_fr) (void)hipStreamSynchronize(c->stream_fr);
     for (hipStream_t sp : c->stream_pg)
         if (sp) (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(c->stream);

@@ -1128,6 +1128,320 @@ __global__ __launch_bounds__(64) void k_seg_fill(uint64_t b0, uint64_t b1, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// r04: FRESH TABLES for the end of a permutation -- a second tier of preparation.
+//
+// Of the ~10 blocks per permutation (of 1M cells) the chain computes itself, 7.4 hold a band change or the permutation's
+// end and cannot be tabulated; the other 2.6 are blocks of the permutation's last bands whose FIRST-tier preparation
+// failed only because its window was too wide for them: a guess made 2-4 launch units ahead is +-13 k states uncertain,
+// which is a third of the band [32768, 65535] (the narrowed windows miss, or the events exceed the table limit).  A guess
+// made from the exact state at the START of the permutation is +-2 k states uncertain when it reaches those blocks.
+// k_fresh runs beside the chain (a handful of workgroups on a stream of their own, for the life of the chain launch): the
+// chain posts the exact state of every block boundary at which a new permutation has begun; each helper takes one of the
+// clean-looking blocks among the last FR_TAIL of that permutation, solves it from the fresh guess, and turns its events
+// into the gap-transfer table of a +-2047 window by walking every entry gap through the event list (with so narrow a
+// window that is cheaper than the rank-select build of k_phi_tbuild, and it is done before the chain arrives).  The chain
+// consults the fresh table when it meets a block it would otherwise compute (or whose first-tier window missed) in the
+// permutation's last FR_REM_MAX steps; what it takes from it is verified by k_block_exact like any prepared block.
+// ------------------------------------------------------------------------------------------------
+#ifndef PHI_FRESH_TABLES
+#define PHI_FRESH_TABLES 0     // r04 NEGATIVE RESULT, kept as a development build (-DPHI_FRESH_TABLES=1; scripts/build_variant.sh): see DESIGN.md 4.3
+#endif
+#define FR_RING 128            // fresh descriptors / tables (the tails of consecutive permutations are ~85 blocks apart)
+#define FR_W 2047              // entry gaps covered per side
+#define FR_WORDS 32            // 64-bit words of a side's table
+#ifndef FR_HELPERS
+#define FR_HELPERS 3
+#ifndef FR_ROUNDS
+#define FR_ROUNDS 2             // blocks per helper and post
+#endif
+#endif
+#define FR_TAIL 12             // candidates: the blocks before the expected end of the permutation
+#define FR_MAX_EV 2048         // events per side
+#define FR_REM_MAX 150000u     // the chain asks for a fresh table when at most this many steps of the permutation are left
+#define FR_POST_REM 120000u    // ... and posts the reference state for the NEXT permutation's tables when this many are left
+#ifndef FR_WINDOW
+#define FR_WINDOW 1.75         // window half-width in units of sqrt(draws since the reference state) (3.6 sigma)
+#endif
+
+struct FreshDesc {
+    unsigned long long G;      // guessed entry state
+    uint32_t cnt, i_in;        // accepts of the base trajectory, steps left in G's permutation
+    uint16_t w_pos, w_neg;     // covered entry gaps per side
+    uint32_t pad_;
+    unsigned long long ready;  // block index + 1 once the table is complete (release / acquire)
+};
+struct FreshCtl {
+    uint32_t seq, done;        // posts so far (chain), id of the last chain launch that has ended
+    unsigned long long post_b[2], post_S[2];   // [seq & 1]: a block boundary at which a permutation has just begun + its exact state
+    unsigned long long post_t[2];              // ... and the wall clock (100 MHz) of the post (diagnostics)
+    unsigned long long diag[9];                // diagnostics (scripts/generator_probe.py)
+};
+static_assert(sizeof(FreshDesc) == 32 && sizeof(FreshCtl) == 128, "fresh-table records");
+
+// Mean-field walk inside ONE permutation, in single precision with the fast intrinsics (a helper has ~5 us for all its
+// guesses; steps < 2^24 are exact in float, and a guess needs +-a few states): the steps left after q more draws from
+// `rem` steps left (0 when the permutation is over), and the draws until it is over.
+__device__ static uint32_t phi_rem_after(uint32_t rem, float q)
+{
+    float i = (float)rem;
+    for (int guard = 0; guard < 40 && q > 0.f && i >= 1.f; ++guard) {
+        const uint32_t m = mask_of((uint32_t)i);
+        const float top = (float)m + 1.f, lo = (float)((m >> 1) + 1);
+        const float need = top * __logf((i + 1.f) / lo);   // draws to leave the band
+        if (need <= q) { q -= need; i = lo - 1.f; }
+        else { i = (i + 1.f) * __expf(-q / top) - 1.f; q = 0.f; }
+    }
+    return q > 0.f || i < 1.f ? 0u : (uint32_t)(i + 0.5f);
+}
+__device__ static float phi_draws_to_finish(uint32_t rem)
+{
+    float q = 0.f, i = (float)rem;
+    for (int guard = 0; guard < 40 && i >= 1.f; ++guard) {
+        const uint32_t m = mask_of((uint32_t)i);
+        const float lo = (float)((m >> 1) + 1);
+        q += ((float)m + 1.f) * __logf((i + 1.f) / lo);
+        i = lo - 1.f;
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_fresh(const uint32_t *__restrict__ raw, uint64_t n_blocks, uint32_t n,
+                                                        uint64_t total_steps, double dpp, FreshCtl *__restrict__ ctl,
+                                                        FreshDesc *__restrict__ fdesc,
+                                                        unsigned long long *__restrict__ ftbits,
+                                                        const unsigned long long *__restrict__ st, uint32_t launch_id)
+{
+    __shared__ BlockShared sh;
+    __shared__ uint32_t shCmd, shSeq, shW, shIin;
+    __shared__ unsigned long long shB, shG, shBref, shSref, shE, shGs[FR_TAIL + 1];
+    __shared__ uint32_t wpk[SCAN_THREADS / 64];
+    __shared__ __align__(16) uint16_t evs[2][FR_MAX_EV];
+    __shared__ __align__(8) uint8_t tab[2][(FR_W + 1) / 8];
+    const uint32_t tau = threadIdx.x, lane = tau & 63, wave = tau >> 6;
+    const uint32_t M = n - 1, top_mask = mask_of(M);
+    uint32_t last = 0;
+    for (;;) {
+        if (tau == 0) {   // wait for a post newer than the last one served, the end of the chain launch, a failure or 1 s
+            uint32_t cmd = 0, seq = 0;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                seq = __hip_atomic_load(&ctl->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (seq != last) break;
+                if (__hip_atomic_load(&ctl->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= launch_id ||
+                    __hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
+                    wall_clock64() - t0 > PHI_WAIT_TICKS) { cmd = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            unsigned long long b_ref = 0, S_ref = total_steps;
+            if (!cmd) {
+                b_ref = ctl->post_b[seq & 1u]; S_ref = ctl->post_S[seq & 1u];
+                if (__hip_atomic_load(&ctl->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) S_ref = total_steps;   // (overwritten meanwhile: next round)
+            }
+            shCmd = cmd; shSeq = seq; shBref = b_ref; shSref = S_ref;
+        }
+        __syncthreads();
+        if (shCmd) return;
+        {   // the guesses of the last FR_TAIL + 1 blocks of this permutation, one lane each (a guess is a dozen logarithms)
+            const unsigned long long b_ref = shBref, S_ref = shSref;
+            if (tau <= FR_TAIL && S_ref < total_steps) {
+                const uint32_t rem_ref = M - (uint32_t)(S_ref % M);
+                // the post is from the END of a permutation (rem_ref steps left); the tables are for the end of the NEXT one
+                const float q_end = phi_draws_to_finish(rem_ref), q_perm = phi_draws_to_finish(M);
+                const unsigned long long e = b_ref + (unsigned long long)((q_end + q_perm) / (float)SCAN_BLOCK);
+                // cell k: block e + 1 - k; its guess = the next permutation's end minus the steps expected to be left there
+                const unsigned long long bk = e + 1 - tau;
+                unsigned long long Gk = ~0ull;
+                const float q = (float)(bk - b_ref) * (float)SCAN_BLOCK - q_end;   // draws into the next permutation
+                if (e + 1 >= b_ref + tau && q > 0.f) {
+                    const uint32_t left = phi_rem_after(M, q);
+                    Gk = S_ref + rem_ref + M - left;     // (left == 0: at or beyond that permutation's end)
+                }
+                shGs[tau] = Gk;
+                if (tau == 0) shE = e;
+            }
+        }
+        __syncthreads();
+        for (uint32_t round = 0; round < FR_ROUNDS; ++round) {   // this helper's blocks of the post, latest first
+        if (tau == 0) {
+            unsigned long long bsel = ~0ull, Gsel = 0;
+            uint32_t wsel = 0, isel = 0;
+            const unsigned long long b_ref = shBref, S_ref = shSref;
+            if (S_ref < total_steps) {
+                // the clean-looking blocks among the last FR_TAIL of this permutation; this helper takes the
+                // (blockIdx.x)-th from the END (the late ones are never prepared by the first tier)
+                const uint32_t rem_ref = M - (uint32_t)(S_ref % M);
+                const unsigned long long perm_end = S_ref + rem_ref + M, e = shE;   // (the end of the NEXT permutation)
+                uint32_t taken = 0;
+                for (uint32_t k = 0; k < FR_TAIL; ++k) {
+                    if (e < b_ref + k) break;
+                    const unsigned long long b = e - k;
+                    if (b + 1 >= n_blocks) continue;
+                    const unsigned long long G = shGs[k + 1], Gnext = shGs[k];   // blocks e - k and e - k + 1
+                    if (G == ~0ull || G >= perm_end || Gnext >= perm_end || Gnext + SCAN_BLOCK >= total_steps) continue;
+                    const double dq = (double)(b - b_ref) * (double)SCAN_BLOCK;
+                    const uint32_t i_in = (uint32_t)(perm_end - G), i_out = (uint32_t)(perm_end - Gnext);
+                    const double wd = FR_WINDOW * sqrt(dq) + 32.0;
+                    const uint32_t w = wd < (double)FR_W ? (uint32_t)wd : (uint32_t)FR_W;
+                    const uint32_t m = mask_of(i_in), low = (m >> 1) + 1;
+                    if (i_out < low + w / 4 || i_in > FR_REM_MAX + SCAN_BLOCK) continue;   // a band change inside (or too early)
+                    if (taken++ == blockIdx.x + FR_HELPERS * round) { bsel = b; Gsel = G; wsel = w; isel = i_in; break; }
+                }
+                if (bsel != ~0ull && __hip_atomic_load(&fdesc[bsel % FR_RING].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bsel + 1)
+                    bsel = ~0ull;   // prepared already (an earlier post of the same permutation)
+            }
+            shB = bsel; shG = Gsel; shW = wsel; shIin = isel;
+            atomicAdd(&ctl->diag[0], 1ull);                                  // diagnostics: rounds, blocks attempted,
+            if (bsel != ~0ull) atomicAdd(&ctl->diag[1], 1ull);               // ... ticks from the post to the start of the work
+            atomicAdd(&ctl->diag[2], (unsigned long long)wall_clock64() - ctl->post_t[shSeq & 1u]);
+        }
+        __syncthreads();
+        if (round == 0) last = shSeq;
+        const unsigned long long b = shB, G = shG;
+        const uint32_t w = shW, i_in = shIin;
+        __syncthreads();     // (everybody has read the cells thread 0 rewrites next time)
+        if (b == ~0ull) continue;
+        // ---- the base trajectory from the fresh guess, as k_phi_events does it ----
+        uint32_t u[SCAN_D];
+        scan_load(raw, b * SCAN_BLOCK, tau, u);
+        ScanRes r;
+        uint32_t excl = 0, total_cnt = 0, parity = 0;
+        bool easy = block_fixed_point(u, G, i_in, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) == 0;
+        const uint32_t mask = mask_of(i_in);
+        const uint32_t cap = mask < M ? mask : M, low = (mask >> 1) + 1;
+        uint32_t w_pos = 0, w_neg = 0;
+        if (easy && i_in >= total_cnt + low) {
+            const uint32_t i_out = i_in - total_cnt;
+            w_pos = w < i_out - low ? w : i_out - low;
+            w_neg = w < cap - i_in ? w : cap - i_in;
+        } else easy = false;
+        uint32_t totP = 0, totN = 0, offP = 0, offN = 0;
+        {
+            uint32_t thr = i_in - excl, np = 0, nn = 0;
+            if (easy) {
+#pragma unroll
+                for (int s = 0; s < SCAN_D; ++s) {
+                    const int32_t d = (int32_t)(thr - (u[s] & mask));
+                    if (d >= 0) { np += ((uint32_t)d < w_pos) ? 1u : 0u; --thr; }
+                    else nn += ((uint32_t)(-d - 1) < w_neg) ? 1u : 0u;
+                }
+            }
+            const uint32_t pk = np | (nn << 16);
+            const uint32_t incl = wave_inclusive_scan(pk);
+            if (lane == 63) wpk[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+                const uint32_t t = wpk[k];
+                before += (k < (int)wave) ? t : 0u;
+                all += t;
+            }
+            const uint32_t ex = before + incl - pk;
+            offP = ex & 0xffffu; offN = ex >> 16;
+            totP = all & 0xffffu; totN = all >> 16;
+        }
+        if (totP > FR_MAX_EV || totN > FR_MAX_EV) easy = false;   // (uniform: totals are the same in every thread)
+        if (easy) {
+            uint32_t thr = i_in - excl;
+#pragma unroll
+            for (int s = 0; s < SCAN_D; ++s) {
+                const int32_t dd = (int32_t)(thr - (u[s] & mask));
+                if (dd >= 0) { if ((uint32_t)dd < w_pos) evs[0][offP++] = (uint16_t)dd; --thr; }
+                else if ((uint32_t)(-dd - 1) < w_neg) evs[1][offN++] = (uint16_t)(-dd - 1);
+            }
+        }
+        __syncthreads();
+        if (tau == 0) atomicAdd(&ctl->diag[easy ? 3 : 4], 1ull);   // diagnostics: base trajectories clean / not clean
+        if (!easy) continue;   // (uniform)
+        const uint64_t slot = b % FR_RING;
+        if (tau == 0) {   // the slot's old table is void from here on
+            __hip_atomic_store(&fdesc[slot].ready, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+        // ---- the table: every entry gap of the window walked through the side's events (draw order) ----
+        // thread (side, t) of the first eight wavefronts owns the gaps 8 t .. 8 t + 8; an event of slack s takes one step
+        // off every gap above s: all of the thread's gaps (a counter), none, or -- rarely -- some of them.  Events are
+        // read eight at a time (a dependent LDS read per event was most of the walk's time)
+        if (tau < 512) {
+            const uint32_t side = tau >> 8, t = tau & 255u;
+            const uint32_t nev = side ? totN : totP;
+            uint32_t a[9], off = 0;
+#pragma unroll
+            for (int k = 0; k <= 8; ++k) a[k] = 8u * t + k;
+            const uint4 *ev8 = reinterpret_cast<const uint4 *>(evs[side]);
+            for (uint32_t e0 = 0; e0 < nev; e0 += 8) {
+                const uint4 pk = ev8[e0 >> 3];
+                const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (e0 + j < nev) {   // (uniform per side: all threads of a wavefront belong to one side)
+                        const uint32_t lim = ((wds[j >> 1] >> (16 * (j & 1))) & 0xffffu) + off;   // gap > slack  <=>  a > slack + off
+                        if (a[0] > lim) ++off;
+                        else if (a[8] > lim) {
+#pragma unroll
+                            for (int k = 0; k <= 8; ++k) a[k] -= (a[k] > lim) ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bits |= (a[k + 1] - a[k]) << k;   // surviving increments (gaps move together: 0 or 1)
+            tab[side][t] = (uint8_t)bits;
+        }
+        __syncthreads();
+        if (tau < 2 * FR_WORDS) {   // 2 x 32 words of 64 bits
+            const uint32_t side = tau / FR_WORDS, wd = tau % FR_WORDS;
+            ftbits[(slot * 2 + side) * FR_WORDS + wd] = *reinterpret_cast<const unsigned long long *>(&tab[side][8 * wd]);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tau == 0) {
+            FreshDesc d;
+            d.G = G; d.cnt = total_cnt; d.i_in = i_in; d.w_pos = (uint16_t)w_pos; d.w_neg = (uint16_t)w_neg; d.pad_ = 0; d.ready = 0;
+            FreshDesc *dst = fdesc + slot;
+            dst->G = d.G; dst->cnt = d.cnt; dst->i_in = d.i_in; dst->w_pos = d.w_pos; dst->w_neg = d.w_neg;
+            __hip_atomic_store(&dst->ready, (unsigned long long)b + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&ctl->diag[5], (unsigned long long)wall_clock64() - ctl->post_t[last & 1u]);   // diagnostics: ticks from the post to "ready"
+        }
+        }   // rounds
+    }
+}
+
+// The chain's side: resolve block bx, entered with S, from its fresh table if there is one that covers S (every thread of
+// the workgroup evaluates it: S stays uniform).  Returns false when there is none.
+// ready_known: the caller has seen ready == bx + 1 already (a relaxed load issued long before): only the acquire fence is
+// needed.  (A slot is rewritten only for a block FR_RING further on, i.e. after the chain has passed this one: no re-check.)
+__device__ __forceinline__ bool fresh_lookup(const FreshDesc *__restrict__ fdesc, const unsigned long long *__restrict__ ftbits,
+                                             uint64_t bx, uint64_t &S, uint32_t &rem, bool ready_known)
+{
+    const uint64_t slot = bx % FR_RING;
+    const FreshDesc *fd = fdesc + slot;
+    if (ready_known) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else if (__hip_atomic_load(&fd->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != bx + 1) return false;
+    const unsigned long long G = fd->G;
+    const uint32_t cnt = fd->cnt, i_in = fd->i_in, w_pos = fd->w_pos, w_neg = fd->w_neg;
+    const int64_t g = (int64_t)S - (int64_t)G;
+    const bool neg = g < 0;
+    const uint64_t idx = (uint64_t)(neg ? -g : g);
+    if (idx > (neg ? w_neg : w_pos)) return false;
+    uint32_t T = 0;
+    if (idx) {
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t c = 0;
+        if (lane < FR_WORDS && (uint64_t)lane * 64u < idx) {
+            const unsigned long long wd = ftbits[(slot * 2 + (neg ? 1 : 0)) * FR_WORDS + lane];
+            const uint32_t d = (uint32_t)idx - lane * 64u;
+            c = (uint32_t)__popcll(wd & sc_low_mask64(d < 64u ? d : 64u));
+        }
+        T = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(c), 63);
+    }
+    S = G + cnt + (unsigned long long)(neg ? -(long long)T : (long long)T);
+    rem = i_in - (uint32_t)(S - G);
+    return true;
+}
+
 // Chain the exact states through blocks [b0, b1) (one workgroup): a SEGMENT of prepared blocks costs one lookup in
 // its (composed) table, which every thread evaluates for itself from LDS; the other blocks the full in-block fixed
 // point.  While a block is computed, the draws of the next block to compute and the tables of the run of segments
@@ -1144,7 +1458,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                                                         bits_t *__restrict__ acc_bits, uint32_t *__restrict__ enter,
                                                         unsigned long long *__restrict__ sblk,
                                                         unsigned long long *__restrict__ st, uint32_t *__restrict__ flags,
-                                                        uint32_t unit0)
+                                                        uint32_t unit0, FreshCtl *__restrict__ fctl /* + descriptors + tables */,
+                                                        uint32_t launch_id)
 {
     __shared__ BlockShared sh;
     __shared__ uint32_t shReady;
@@ -1160,13 +1475,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     const uint32_t M = n - 1, top_mask = mask_of(M);
     uint64_t S = st[0];
     if (S >= total_steps || st[1] != B0 || B1 > n_blocks) {  // job complete, or an earlier launch gave up (uniform)
-        if (tau == 0) __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // no gate waits for us
+        if (tau == 0) {
+            __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // no gate waits for us
+            if (fctl) __hip_atomic_store(&fctl->done, launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // nor k_fresh
+        }
         return;
+    }
+    // the exact state S_ at the boundary IN FRONT OF block bx_, the first one seen with at most FR_POST_REM steps of the
+    // current permutation left: the reference for the fresh tables of the NEXT permutation's end (k_fresh has a whole
+    // permutation of chain time, ~100 us, to build them; the uncertainty grows only with the square root of the distance)
+#define PHI_POST(bx_, S_)                                                                                     \
+    if (fctl && tau == 0 && !cn[6]) {                                                                         \
+        cn[6] = 1;                                                                                            \
+        const uint32_t ps_ = ++cn[5];                                                                         \
+        fctl->post_b[ps_ & 1u] = (bx_);                                                                       \
+        fctl->post_S[ps_ & 1u] = (S_);                                                                        \
+        fctl->post_t[ps_ & 1u] = (unsigned long long)wall_clock64();                                          \
+        __hip_atomic_store(&fctl->seq, ps_, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);                      \
     }
     uint32_t parity = 0;
     int failed = 0;
-    uint64_t endpos = 0;
-    uint32_t n_easy = 0, n_hard = 0, n_seg = 0, n_slow = 0;
+    __shared__ unsigned long long shEnd;   // (raw position of the job's last step, seen by at most one thread of one launch)
+    if (tau == 0) shEnd = 0;
+    // counters of thread 0 live in LDS (the kernel sits at its 128-VGPR cap): [0] blocks by lookup, [1] computed, [2] segment
+    // lookups, [3] slow paths, [4] blocks by fresh table, [5] posts to k_fresh
+    __shared__ uint32_t cn[7];   // ... [6] the current permutation has been posted
+    if (tau < 7) cn[tau] = tau == 5 && fctl ? fctl->seq : 0u;
+    __syncthreads();
 #ifdef PHI_PROFILE
     unsigned long long pf_easy = 0, pf_hard = 0;
 #endif
@@ -1225,6 +1560,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     ulonglong2 treg;
     uint32_t un[SCAN_D];
     uint32_t rel = 0, h = nxt[0];   // rel: next block to resolve; h: the next block the chain computes itself (>= rel)
+    // the "ready" word (low half: block + 1) of block h's fresh table, asked for as soon as h is known -- one item (a
+    // fixed point, microseconds) before it is looked at: a table that is not there then costs nothing
+#if PHI_FRESH_TABLES
+#define PHI_FRESH_ASK(hh)                                                                                                    \
+    fr_ready = (fctl && (hh) < nb) ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(                                   \
+                   &reinterpret_cast<const FreshDesc *>(fctl + 1)[(b0 + (hh)) % FR_RING].ready), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t fr_ready;
+#else
+#define PHI_FRESH_ASK(hh)
+#endif
+    PHI_FRESH_ASK(h)
     PHI_STAGE_LOAD(rel)
     if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
     for (;;) {
@@ -1261,13 +1607,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                 }
                 if (tau == 0) { sblk[b0 + rel] = S; segmode[b0 + rel] = 1; }
                 int64_t e = (int64_t)sq.exit0 + (neg ? -(int64_t)T : (int64_t)T);
-                if (fault && n_easy == 0) e += 1;  // testing: the verification must catch this
+                if (fault && cn[0] == 0) e += 1;  // testing: the verification must catch this
                 S = sq.G + (unsigned long long)e;
                 rem = sq.i_in - (uint32_t)e;       // no trajectory of the window leaves G's permutation
-                n_easy += sq.len;
-                ++n_seg;
+                if (tau == 0) { cn[0] += sq.len; ++cn[2]; }
                 rel += sq.len;
             }
+            // ... and behind them a block the chain would compute itself: at the end of a permutation a FRESH table may
+            // cover it (k_fresh; wavefront 0 alone evaluates it: the lookup's registers are not live in the fixed point)
+#if PHI_FRESH_TABLES
+            while (fctl && !miss0 && rel < nb && sg[rel].kind == 0 && rem <= FR_REM_MAX && (rel != h || fr_ready == (uint32_t)(b0 + rel + 1))) {
+                const uint64_t S_in = S;
+                if (tau == 0) {   // diagnostics: lookups tried, ticks since the last post, how far its block is from the slot's
+                    atomicAdd(&fctl->diag[6], 1ull);
+                    atomicAdd(&fctl->diag[7], (unsigned long long)wall_clock64() - fctl->post_t[cn[5] & 1u]);
+                    const unsigned long long rd = reinterpret_cast<const FreshDesc *>(fctl + 1)[(b0 + rel) % FR_RING].ready;
+                    if (rd == b0 + rel + 1) atomicAdd(&fctl->diag[8], 1ull);   // a table for exactly this block exists
+                }
+                if (!fresh_lookup(reinterpret_cast<const FreshDesc *>(fctl + 1),
+                                  reinterpret_cast<const unsigned long long *>(reinterpret_cast<const FreshDesc *>(fctl + 1) + FR_RING),
+                                  b0 + rel, S, rem, rel == h)) break;
+                if (tau == 0) { sblk[b0 + rel] = S_in; hardmask[b0 + rel] = 0; ++cn[0]; ++cn[4]; }
+                ++rel;
+            }
+#endif
             if (tau == 0) { shS = S; shRem = rem; shRel = rel | (miss0 ? 0x80000000u : 0u); }
         }
         __syncthreads();
@@ -1275,6 +1638,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         rem = shRem;
         rel = shRel & 0x7fffffffu;
         const bool miss = (shRel >> 31) != 0;
+#if PHI_FRESH_TABLES
+        if (rem <= FR_POST_REM) PHI_POST(b0 + rel, S)
+#endif
+        if (rel > h) {   // a fresh table resolved the block whose draws were prefetched: the next one to compute, then
+            h = nxt[rel];
+            if (h < nb) scan_load(raw, (b0 + h) * SCAN_BLOCK, tau, un);
+            PHI_FRESH_ASK(h)
+        }
 #ifdef PHI_PROFILE
         const long long pf_ts = clock64();
 #endif
@@ -1294,8 +1665,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                     if (tau == 0) { sblk[bx] = S; hardmask[bx] = 0; }
                     S = d.G + d.cnt + (unsigned long long)(neg ? -(long long)T : (long long)T);
                     rem = d.i_in - (uint32_t)(S - d.G);
-                    ++n_easy;
+                    if (tau == 0) ++cn[0];
                 } else {
+                    // (a fresh table is not consulted here: a second inlined copy of the lookup made the kernel spill)
                     uint32_t u[SCAN_D];
                     scan_load(raw, bx * SCAN_BLOCK, tau, u);
                     ScanRes r;
@@ -1304,14 +1676,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                     acc_bits[bx * SCAN_THREADS + tau] = r.bits;
                     enter[bx * SCAN_THREADS + tau] = excl;
                     if (tau == 0) { sblk[bx] = S; hardmask[bx] = 1; }
-                    if (r.end) endpos = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
+                    if (r.end) shEnd = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
                     S += total_cnt;
-                    rem = rem_advance(rem, total_cnt, M);
-                    ++n_hard;
+                    const uint32_t rem_new = rem_advance(rem, total_cnt, M);
+#if PHI_FRESH_TABLES
+                    if (rem_new > rem && tau == 0) cn[6] = 0;   // a new permutation: not posted yet
+#endif
+                    rem = rem_new;
+                    if (tau == 0) ++cn[1];
                 }
             }
-            if (tau == 0) segmode[b0 + first] = 2;   // k_seg_fill has nothing to add here
-            ++n_slow;
+            if (tau == 0) { segmode[b0 + first] = 2; ++cn[3]; }   // k_seg_fill has nothing to add here
 #ifdef PHI_PROFILE
             if (tau == 0) { atomicAdd(&g_phi_prof[21], (unsigned long long)(clock64() - pf_ts)); atomicAdd(&g_phi_prof[22], 1ull); }
 #endif
@@ -1331,8 +1706,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         }
         // ---- block rel: computed by the chain itself ----
         const uint32_t x = rel;
-        uint32_t u[SCAN_D];
         const uint32_t hN = nxt[x + 1];
+        uint32_t u[SCAN_D];
         if (x == h) {
 #pragma unroll
             for (int q = 0; q < SCAN_D; ++q) u[q] = un[q];
@@ -1342,6 +1717,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         // on their way while block x is computed: the tables of the run behind it and the draws of the block after that
         PHI_STAGE_LOAD(x + 1)
         if (x == h && hN < nb) scan_load(raw, (b0 + hN) * SCAN_BLOCK, tau, un);
+        PHI_FRESH_ASK(hN)     // (for the block after this one; this block's word has been used)
         ScanRes r;
         uint32_t excl, total_cnt;
 #ifdef PHI_PROFILE
@@ -1361,10 +1737,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         acc_bits[bx * SCAN_THREADS + tau] = r.bits;
         enter[bx * SCAN_THREADS + tau] = excl;
         if (tau == 0) { sblk[bx] = S; hardmask[bx] = 1; }
-        if (r.end) endpos = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
+        if (r.end) shEnd = bx * SCAN_BLOCK + (uint64_t)tau * SCAN_D + r.end;
         S += total_cnt;
-        rem = rem_advance(rem, total_cnt, M);
-        ++n_hard;
+        {
+            const uint32_t rem_new = rem_advance(rem, total_cnt, M);
+#if PHI_FRESH_TABLES
+            if (rem_new > rem && tau == 0) cn[6] = 0;   // a new permutation: not posted yet
+#endif
+            rem = rem_new;
+        }
+        if (tau == 0) ++cn[1];
 #ifdef PHI_PROFILE
         pf_hard += (unsigned long long)(clock64() - pf_t1);
 #endif
@@ -1379,19 +1761,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
     }
     }  // units
 #undef PHI_STAGE_LOAD
-    if (endpos) st[3] = endpos;
+#undef PHI_FRESH_ASK
+#undef PHI_POST
+    __syncthreads();
     if (tau == 0) {
+        if (shEnd) st[3] = shEnd;
         const uint64_t b = b_next;
         st[0] = S;
         st[1] = b;
 #ifdef PHI_PROFILE
         st[6] += (pf_easy >> 6) | ((pf_hard >> 6) << 32);   // clocks / 64 of thread 0: lookup phases, computed blocks
 #else
-        st[6] += n_seg;   // segment lookups
+        st[6] += cn[2];   // segment lookups
 #endif
-        st[7] += n_slow;  // segments whose window missed the entry state
-        st[4] += n_easy;
-        st[5] += n_hard;
+        st[7] += (unsigned long long)cn[3] | ((unsigned long long)cn[4] << 32);  // segments whose window missed the entry state | blocks resolved by a fresh table
+        st[4] += cn[0];
+        st[5] += cn[1];
         sblk[b] = S;  // entry state of the next block (sblk holds n_blocks + 1 entries)
         unsigned long long f = 0;  // (k_block_exact of the previous chunk may be raising its own flag right now)
         if (failed) f |= 1ull;
@@ -1400,6 +1785,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
         if (f) atomicOr(st + 2, f);
         if (f || gave_up || S >= total_steps)  // nothing more will come from the chain: release every gate
             __hip_atomic_store(flags, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (fctl) __hip_atomic_store(&fctl->done, launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // k_fresh of this launch ends
     }
 }
 
@@ -1671,6 +2057,10 @@ int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, 
         SC_TRY(c->pg_ctbits.ensure(sizeof(unsigned long long) * (size_t)PHI_RING * 2 * PHI_WORDS, &c->mem));
         SC_TRY(c->pg_segmode.ensure((size_t)n_blocks + 1, &c->mem));
         SC_TRY(c->pg_seglist.ensure(sizeof(uint32_t) * (size_t)PHI_FLAG_SLOTS * (1 + PHI_UNIT), &c->mem));
+        // fresh tables: [control | descriptors | tables]
+        SC_TRY(c->pg_fresh.ensure(sizeof(FreshCtl) + sizeof(FreshDesc) * FR_RING + sizeof(unsigned long long) * FR_RING * 2 * FR_WORDS, &c->mem));
+        SC_HIP(hipMemsetAsync(c->pg_fresh.p, 0, sizeof(FreshCtl) + sizeof(FreshDesc) * FR_RING, s));
+        if (!c->stream_fr) SC_HIP(hipStreamCreateWithFlags(&c->stream_fr, hipStreamNonBlocking));
         SC_HIP(hipMemsetAsync(c->pg_segmode.p, 0, (size_t)n_blocks + 1, s));
         int prio_lo = 0, prio_hi = 0;  // the generator is the critical path of its callers (plain streams if refused)
         const bool prio = getenv("SC_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
@@ -1789,12 +2179,24 @@ int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipSt
             job->B_done = b1;
             job->unit_no = u + 1;
         }
+        // the fresh-table helpers of this chain launch (their own stream; they end with the chain launch)
+        static const bool no_fresh = !PHI_FRESH_TABLES || getenv("SC_NO_FRESH") != nullptr;   // development build only; A/B switch
+        FreshCtl *fctl = no_fresh ? nullptr : reinterpret_cast<FreshCtl *>(c->pg_fresh.p);
+        FreshDesc *fdesc = no_fresh ? nullptr : reinterpret_cast<FreshDesc *>(reinterpret_cast<char *>(c->pg_fresh.p) + sizeof(FreshCtl));
+        unsigned long long *ftbits = no_fresh ? nullptr : reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(fdesc) + sizeof(FreshDesc) * FR_RING);
+        const uint32_t launch_id = (uint32_t)job->chunk_no + 1;
+        if (fctl) {
+            if (job->chunk_no == 0) SC_HIP(hipStreamWaitEvent(c->stream_fr, c->pg_ev[32], 0));   // (the raw stream and the zeroed control block)
+            hipLaunchKernelGGL(k_fresh, dim3(FR_HELPERS), dim3(SCAN_THREADS), 0, c->stream_fr, c->pg_raw.as<uint32_t>(), n_blocks,
+                               (uint32_t)job->n, job->total_steps, job->draws_per_perm, fctl, fdesc, ftbits, st, launch_id);
+        }
         hipLaunchKernelGGL(k_chain, dim3(1), dim3(SCAN_THREADS), 0, s, c->pg_raw.as<uint32_t>(), n_blocks,
                            (uint32_t)job->n, job->total_steps, g0, B_end, target,
                            c->pg_desc.as<PhiDesc>(), c->pg_tbits.as<unsigned long long>(), c->pg_seg.as<PhiSeg>(),
                            c->pg_ctbits.as<unsigned long long>(), c->pg_hard.as<uint8_t>(), c->pg_segmode.as<uint8_t>(),
                            (c->pg_mode == 2 && u_first == 0) ? 1 : 0, c->pg_bits.as<bits_t>(),
-                           c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st, flags, (uint32_t)u_first);
+                           c->pg_enter.as<uint32_t>(), c->pg_sblk.as<unsigned long long>(), st, flags, (uint32_t)u_first,
+                           fctl, launch_id);
         SC_HIP(hipGetLastError());
         // the verification / expansion of this chunk reads the entry states k_seg_fill leaves on the preparation streams
         for (unsigned q = 0; q < PHI_STREAMS; ++q)
@@ -2045,6 +2447,7 @@ static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_
     SC_HIP(hipStreamSynchronize(c->stream));
     for (hipStream_t sp : c->stream_pg)
         if (sp) SC_HIP(hipStreamSynchronize(sp));
+    if (c->stream_fr) SC_HIP(hipStreamSynchronize(c->stream_fr));
     return permgen_finish(c, &job, state6);
 }
 
