@@ -239,9 +239,10 @@ def main() -> None:
                     help="skip the uint16- / float32-source repeats of the step (value_uint16_source, value_float32_source)")
     ap.add_argument("--no-alone", action="store_true",
                     help="skip roofline.alone (counter passes: its launches would be averaged into the per-launch traffic)")
-    ap.add_argument("--source-bits", type=int, default=8, choices=(8, 16, 32, 64),
+    ap.add_argument("--source-bits", type=int, default=8, choices=(4, 8, 16, 32, 64),
                     help="narrowest exact copy of the expression values the permutation kernel may gather "
-                         "(8 / 16: uint8 / uint16 for count data, 32: float32 raw values, 64: the general fp64 kernel)")
+                         "(4: nibble slots for count data when they take fewer rows, 8 / 16: uint8 / uint16 for count data, "
+                         "32: float32 raw values, 64: the general fp64 kernel)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and exchange through files (RCCL refuses duplicate "
                          "devices); exercises the N > 1 code path on a 1-GPU box; never a measurement")
@@ -365,6 +366,7 @@ def main() -> None:
     # and beside the generator's traffic; this is the kernel's own rate.  Reported as roofline.alone, never as `value`.
     timed_bits = ctx.moran_source_bits()
     timed_lag_bits = ctx.moran_lag_bits()
+    timed_groups = ctx.moran_row_groups()
     alone = None
     if rank == 0 and len(batches) == 1 and not rehearse and P >= 128 and not args.no_alone:
         ctx.reset_timers()
@@ -374,17 +376,20 @@ def main() -> None:
         if a_cnt:
             alone = (a_ms / a_cnt, 128)
 
-    def kernel_roofline(kern_ms, kern_launches, steps, bits, lag_bits=64):
+    def kernel_roofline(kern_ms, kern_launches, steps, bits, lag_bits=64, row_groups=None):
         """Bytes the scoring kernel's formulation has to move per launch (its algorithmic bytes) over its average
         HIP-event launch time.  (1) per step: one 128-byte row of raw values + one 4-byte index per (permutation,
         cell, gene group of 128 / 64 / 32 / 16 genes) and the lag rows of every gene once per launch (a launch =
         one chunk of permutations x all gene groups; fp64, or -- r04, count batches -- the 16-bit neighbour sums).  (2) SURVEY 8(d)'s streaming model (16 B per (permutation, gene,
         cell) + 4 B per (permutation, cell)) as an EFFECTIVE rate: the kernel moves fewer bytes than the model."""
-        genes_per_row = {8: 128, 16: 64, 32: 32, 64: 16}[bits]
+        genes_per_row = {4: 256, 8: 128, 16: 64, 32: 32, 64: 16}[bits]   # (4: nibble SLOTS; a gene with counts >= 16 takes two)
         per_step = max(kern_launches // max(steps, 1), 1)
         avg = kern_ms / max(kern_launches, 1)
         g_pad = -(-batch // genes_per_row) * genes_per_row * len(batches)
         grp = g_pad // genes_per_row
+        if bits == 4 and row_groups:
+            grp = row_groups * len(batches)
+            g_pad = grp * genes_per_row
         step_bytes = grp * (P * n * (128.0 + 4.0)) + per_step * n * (lag_bits / 8.0) * g_pad
         ach = step_bytes / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
         eff = (P * G_mine * n * 16.0 + P * n * 4.0) / per_step / (avg * 1e-3) / 1e9 if kern_launches else 0.0
@@ -395,8 +400,8 @@ def main() -> None:
     # batch): what a panel with counts >= 256 (uint16 rows, 64 genes each) or a log-normalised float matrix (float32
     # rows, 32 genes each) pays.  The statistics are those of the timed run (lattice genes: same integers).
     other_sources = {}
-    if rank == 0 and world == 1 and len(batches) == 1 and not rehearse and not args.no_other_sources and args.source_bits == 8:
-        for bits_alt in (16, 32):
+    if rank == 0 and world == 1 and len(batches) == 1 and not rehearse and not args.no_other_sources and args.source_bits <= 8:
+        for bits_alt in ((8, 16, 32) if timed_bits == 4 else (4, 16, 32)):
             ctx.set_moran_source_bits(bits_alt)
             step()
             ctx.sync()
@@ -407,7 +412,7 @@ def main() -> None:
             ctx.sync()
             dt = time.perf_counter() - t1
             k_ms, k_cnt = ctx.kernel_time(_lib.K_MORAN_PERM)
-            rf = kernel_roofline(k_ms, k_cnt, 3, bits_alt, ctx.moran_lag_bits())
+            rf = kernel_roofline(k_ms, k_cnt, 3, bits_alt, ctx.moran_lag_bits(), ctx.moran_row_groups())
             other_sources[bits_alt] = {
                 "value": G_total * 3 / dt, "ms_per_step": dt / 3 * 1e3, "steps": 3, "source_bits": ctx.moran_source_bits(),
                 "roofline": {"achieved": rf["achieved"], "frac": rf["achieved"] / HBM_PEAK_GBS, "avg_launch_ms": rf["avg_ms"],
@@ -422,7 +427,7 @@ def main() -> None:
         value = G_total * args.steps / elapsed
         source_bits = timed_bits
         kernel_name = "k_moran_score"
-        rf = kernel_roofline(perm_ms, perm_launches, args.steps, source_bits, timed_lag_bits)
+        rf = kernel_roofline(perm_ms, perm_launches, args.steps, source_bits, timed_lag_bits, timed_groups)
         launches_per_step, avg_ms, G_pad, groups = rf["launches_per_step"], rf["avg_ms"], rf["g_pad"], rf["groups"]
         kernel_bytes, achieved, effective = rf["launch_bytes"], rf["achieved"], rf["effective"]
         # (3) PMC counters of the same kernel build, collected by scripts/pmc_traffic.py (separate --pmc passes)
@@ -460,7 +465,8 @@ def main() -> None:
                                    + (" (BASELINE configs[1])" if (n, genes_arg, P, k, strong) == (1_000_000, 500, 1000, 15, False)
                                       else " (BASELINE configs[3])" if (n, genes_arg, P, k, strong) == (5_000_000, 2000, 1000, 15, True)
                                       else " (non-default size)"),
-                       "expression_source": {8: "uint8 (counts < 256)", 16: "uint16 (counts)", 32: "float32", 64: "float64"}[source_bits],
+                       "expression_source": {4: "4-bit slots (counts < 16 one slot, counts < 256 two)", 8: "uint8 (counts < 256)",
+                                             16: "uint16 (counts)", 32: "float32", 64: "float64"}[source_bits],
                        "cells": n, "genes_per_gpu": G_mine, "genes_total": G_total, "k": k, "perms": P,
                        "parallelism": f"gene-shard x{world}, one RCCL all-gather of (I, p)"
                                       + (" [file transport, rehearsal]" if rehearse else "")},
@@ -497,7 +503,7 @@ def main() -> None:
             "device_mem_bytes_rank0": mem_peak,
             "nccl_ranks": comm_ranks,
         }
-        for bits_alt, name in ((16, "uint16"), (32, "float32")):
+        for bits_alt, name in ((4, "4bit"), (8, "uint8"), (16, "uint16"), (32, "float32")):
             if bits_alt in other_sources:
                 line[f"value_{name}_source"] = other_sources[bits_alt]["value"]
                 line[f"{name}_source"] = other_sources[bits_alt]

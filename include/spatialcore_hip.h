@@ -71,7 +71,10 @@ int sc_debug_copy(sc_ctx *ctx, int which, int64_t offset_bytes, void *out, int64
  * the same operands and adds the same products in the same order: a gene's statistics do not depend on the width, i.e.
  * not on the genes it is loaded with.  Lattice genes (integer counts on a graph whose weights are all equal, e.g. kNN):
  * scored as the exact integer sum_j S_j x[inv_p(j)] (S = unweighted neighbour sums), #{sims >= I} decided on integers.
- * min_bits (8, 16, 32 or 64; default 8) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
+ * r04, opt-in (min_bits = 4): 4-bit slots, 256 per row, when that takes fewer rows than uint8 (a count below 16 is one
+ * nibble, a count up to 255 the exact sum of two nibble pseudo-genes, x = lo + 16 hi; integer sums) -- same results bit for
+ * bit; measured: the kernel alone 15 % faster, the pipelined step slower (heavier set-up), hence not the default.
+ * min_bits (4, 8, 16, 32 or 64; default 8) forbids the narrower sources; sc_ctx_moran_source_bits reports what the last
  * scoring call gathered. */
 int sc_ctx_set_moran_source_bits(sc_ctx *ctx, int min_bits);
 int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
@@ -79,6 +82,8 @@ int sc_ctx_moran_source_bits(sc_ctx *ctx, int *bits);
  * all-count uint8 batch on an equal-weight graph kept its neighbour sums as the 16-bit integers they are (converted to
  * the same fp64 values inside the kernel), else 64.  Diagnostic: bench.py prices the kernel's compulsory bytes with it. */
 int sc_ctx_moran_lag_bits(sc_ctx *ctx, int *bits);
+/* ... and the number of 128-byte rows it gathers per (permutation, cell): the gene groups of the source width in use. */
+int sc_ctx_moran_row_groups(sc_ctx *ctx, int *groups);
 /* How the device generator of sc_perm_generate / sc_moran_seeded resolves numpy's rejection stream
  * (results are identical in every mode): 0 = automatic (block-parallel scan for n >= 131072, verified on the
  * device, sequential scan otherwise or when the verification fails), 1 = sequential scan only,

@@ -40,6 +40,7 @@ SYMBOLS = {
     "sc_ctx_set_moran_source_bits": [_P, c_int],
     "sc_ctx_moran_source_bits": [_P, _P],
     "sc_ctx_moran_lag_bits": [_P, _P],
+    "sc_ctx_moran_row_groups": [_P, _P],
     "sc_ctx_permgen_stats": [_P, _P, _P, _P, _P, _P],
     "sc_ctx_device_mem": [_P, POINTER(c_int64)],
     "sc_debug_copy": [_P, c_int, c_int64, _P, c_int64],
@@ -236,15 +237,22 @@ class Context:
         _check(self._lib.sc_ctx_set_permgen_mode(self._h, int(mode)))
 
     def set_moran_source_bits(self, min_bits: int) -> None:
-        """Narrowest exact source copy the permutation kernels may gather: 8 (default: uint8 when every value is an
-        integer count < 256), 16 (uint16, counts < 65536), 32 (float32) or 64 (the fp64 tiles)."""
+        """Narrowest exact source copy the permutation kernels may gather: 4 (opt-in: nibble slots for count data when they
+        take fewer rows than uint8), 8 (default: uint8 when every value is an integer count < 256), 16 (uint16, counts <
+        65536), 32 (float32) or 64 (the fp64 tiles)."""
         _check(self._lib.sc_ctx_set_moran_source_bits(self._h, int(min_bits)))
 
     def moran_source_bits(self) -> int:
-        """Source width the last scoring call gathered: 8 / 16 (uint8 / uint16 counts), 32 (float32 raw values) or
-        64 (fp64 kernel)."""
+        """Source width the last scoring call gathered: 4 (nibble slots) / 8 / 16 (uint8 / uint16 counts), 32 (float32 raw
+        values) or 64 (fp64 kernel)."""
         v = c_int(0)
         _check(self._lib.sc_ctx_moran_source_bits(self._h, byref(v)))
+        return v.value
+
+    def moran_row_groups(self) -> int:
+        """128-byte rows the last scoring call gathered per (permutation, cell)."""
+        v = c_int(0)
+        _check(self._lib.sc_ctx_moran_row_groups(self._h, byref(v)))
         return v.value
 
     def moran_lag_bits(self) -> int:

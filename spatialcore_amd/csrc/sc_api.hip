@@ -179,7 +179,7 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
                     &c->lee_b, &c->lee_out, &c->lee_pairs, &c->lee_U, &c->lee_Zc, &c->lee_Uc, &c->lee_part, &c->lee_obs, &c->lee_cnt,
                     &c->lee_rowmap, &c->lee_lperm, &c->g_slag, &c->g_xsum, &c->g_flags, &c->g_xmax, &c->g_lat, &c->g_meanc, &c->g_seff, &c->g_corr, &c->g_thr, &c->sims_raw, &c->g_order, &c->g_rank, &c->g_indices_r, &c->g_w32, &c->g_erow_r, &c->lm_ys, &c->lm_tab, &c->s0_tmp, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_flags, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
-                    &c->pg_desc, &c->pg_tbits, &c->pg_events, &c->pg_hard, &c->pg_seg, &c->pg_ctbits, &c->pg_segmode, &c->pg_seglist, &c->pg_fresh,
+                    &c->pg_desc, &c->pg_tbits, &c->pg_events, &c->pg_hard, &c->pg_seg, &c->pg_ctbits, &c->pg_segmode, &c->pg_seglist, &c->pg_fresh, &c->nib_map,
                     &c->np_cnt, &c->np_comp, &c->np_leaves, &c->np_leafsum};
     for (DBuf *b : bufs) b->release(&c->mem);
     for (int k = 0; k < SC_K_COUNT_; ++k) {
@@ -283,8 +283,8 @@ int sc_ctx_permgen_note(sc_ctx *c, const char **message)
 int sc_ctx_set_moran_source_bits(sc_ctx *c, int min_bits)
 {
     SC_REQUIRE(c, SC_ERR_INVALID, "null context");
-    SC_REQUIRE(min_bits == 8 || min_bits == 16 || min_bits == 32 || min_bits == 64, SC_ERR_INVALID,
-               "sc_ctx_set_moran_source_bits: %d not in {8, 16, 32, 64}", min_bits);
+    SC_REQUIRE(min_bits == 4 || min_bits == 8 || min_bits == 16 || min_bits == 32 || min_bits == 64, SC_ERR_INVALID,
+               "sc_ctx_set_moran_source_bits: %d not in {4, 8, 16, 32, 64}", min_bits);
     c->source_bits_min = min_bits;
     return SC_OK;
 }
@@ -300,6 +300,14 @@ int sc_ctx_moran_lag_bits(sc_ctx *c, int *bits)
 {
     SC_REQUIRE(c && bits, SC_ERR_INVALID, "null pointer");
     *bits = c->lag_u16 ? 16 : 64;
+    return SC_OK;
+}
+
+int sc_ctx_moran_row_groups(sc_ctx *c, int *groups)
+{
+    SC_REQUIRE(c && groups, SC_ERR_INVALID, "null pointer");
+    const int64_t gp = c->narrow_bits == 8 ? 128 : c->narrow_bits == 16 ? 64 : c->narrow_bits == 32 ? 32 : 16;
+    *groups = c->narrow_bits == 4 ? c->nib_groups : (int)ceil_div64(c->e_tiles * SC_TILE, gp);
     return SC_OK;
 }
 

@@ -130,11 +130,13 @@ struct sc_ctx {
     DBuf X, Z, Lag;      // [tile][cell][16] fp64: raw, centred/standardised, lagged
     DBuf X32;            // the raw values again in the narrowest exact type, one 128-byte row per cell and gene group:
                          // 32 float (float32-exact values), 64 uint16 (counts < 65536) or 128 uint8 (counts < 256) per row
+    int nib_groups = 0;         // > 0: the last moran_prepare built the 4-bit source (256 nibble slots per row) with this many row groups
+    DBuf nib_map;               // ... its slot map: [padded genes] slot of the gene's high nibble (-1: none) | the genes that have one
     bool lag_u16 = false;       // the last moran_prepare left Lag as 16-bit neighbour sums ([group][cell][64 words]; uint8 source only)
     int narrow_bits = 64;       // element width of the narrow copy the last moran_prepare built: 8, 16, 32 (64: none, the fp64 Z tiles are gathered)
     int n_cus = 0;              // compute units of the device (filled on first use)
     int score_leave_cus = 0;    // compute units the persistent scoring kernel leaves empty (> 0 only while a generator runs beside it)
-    int source_bits_min = 8;    // narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
+    int source_bits_min = 8;    // (4: the nibble source, opt-in -- measured slower at the step level) narrowest source the scoring kernels may gather (sc_ctx_set_moran_source_bits)
     int last_source_bits = 0;   // ... and what the last scoring launch gathered (64 = fp64 kernel)
     DBuf e_tmp_indptr, e_tmp_indices, e_tmp_data, e_colmap;
     DBuf g_mean, g_var, g_z2, g_scale, g_Inum, g_I, red_tmp;  // per padded gene

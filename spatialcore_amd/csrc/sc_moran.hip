@@ -1012,8 +1012,10 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
     const double *__restrict__ mean, const int32_t *__restrict__ inv, double *__restrict__ partial, int64_t n,
     int64_t pstride, int n_perm, int64_t cells_per_split, int n_splits, int n_groups)
 {
-    static_assert((BITS == 8 || BITS == 16 || BITS == 32 || BITS == 64) && (CB == 4 || CB == 8), "source width / block size");
-    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : BITS == 32 ? 2 : 1;
+    static_assert((BITS == 4 || BITS == 8 || BITS == 16 || BITS == 32 || BITS == 64) && (CB == 4 || CB == 8), "source width / block size");
+    // BITS == 4 (r04): 256 nibble slots per row; TG = the lane's four 16-byte pieces of uint16 operands per cell (8 slots each)
+    constexpr bool NIB = BITS == 4;
+    constexpr int TG = BITS == 8 ? 8 : BITS == 16 ? 4 : BITS == 32 ? 2 : NIB ? 4 : 1;
     constexpr bool CENTER = BITS == 16 || BITS == 32;
     constexpr int ROW = TG * 8;
     constexpr int NI = CB / 4;
@@ -1049,7 +1051,10 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         const int tiles_left = tiles16 - TG * grp;
         const double *lag_g = Lag + (int64_t)TG * grp * tile_elems;
         // (a padded last group re-reads its first tile for the missing ones; those sums are never used)
-        const double2 *lsrc = reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (pid & 7);
+        // (NIB: the operand rows are [group][cell][ROW pieces] -- 512 bytes of uint16 per cell --, moved as 16-byte pieces like lag tiles)
+        const double2 *lsrc = NIB ? reinterpret_cast<const double2 *>(Lag) + (int64_t)grp * n * ROW + (pid % ROW)
+                                  : reinterpret_cast<const double2 *>(lag_g + (int64_t)(ltile < tiles_left ? ltile : 0) * tile_elems) + (pid & 7);
+        constexpr int LSTRIDE = NIB ? ROW : 8;      // pieces from one cell's row to the next
         const uint32_t *lag16_g = reinterpret_cast<const uint32_t *>(Lag) + (int64_t)grp * n * ROW;   // L16: [cell][ROW] words
         const uint32_t *lsrc16 = lag16_g + (pid % ROW);
         double m[CENTER ? TG : 1][2], acc[TG][2];
@@ -1061,6 +1066,9 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             }
             acc[t][0] = acc[t][1] = 0.0;
         }
+        uint32_t ai[NIB ? 32 : 1];   // NIB: integer sums of the lane's 32 slots
+#pragma unroll
+        for (int k2 = 0; k2 < (NIB ? 32 : 1); ++k2) ai[k2] = 0u;
         const int64_t nsb = (c1 - c0) / SCORE_SB;   // whole super-blocks of the split (the rest: tail loop below)
         const int64_t nblk = nsb * SPS;
 
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         auto load_lag = [&](int64_t sb) {
             const int64_t ss = sb < nsb ? sb : nsb - 1;
             if constexpr (L16) lh = lsrc16[(c0 + ss * SCORE_SB + lcell) * ROW];
-            else lg = lsrc[(c0 + ss * SCORE_SB + lcell) * 8];
+            else lg = lsrc[(c0 + ss * SCORE_SB + lcell) * LSTRIDE];
         };
         auto gather = [&](uint4 (&x)[CB], const int4 (&id)[NI]) {
 #pragma unroll
@@ -1093,6 +1101,17 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
         };
         auto mul_cell = [&](const uint4 &x, const double2 *lr) {
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+            if constexpr (NIB) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint4 sp = *reinterpret_cast<const uint4 *>(&lr[t * 8]);   // the 8 uint16 operands of slots 64 t + 8 q + e
+                    const uint32_t sw[4] = {sp.x, sp.y, sp.z, sp.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        ai[t * 8 + e] += __umul24((w[t] >> (4 * e)) & 15u, (sw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                }
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 const double2 l = lr[t * 8];
@@ -1121,7 +1140,10 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             __builtin_amdgcn_sched_barrier(0);
             const double2 *lr = &lds_lag[sb & 1][k * CB * ROW + q];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) mul_cell(cur[c], lr + c * ROW);
+            for (int c = 0; c < CB; ++c) {
+                mul_cell(cur[c], lr + c * ROW);
+                if constexpr (NIB) __builtin_amdgcn_sched_barrier(0);   // (one cell's operand pieces at a time: hoisted together they spill)
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (k == SPS - 1) {
                 park((int)((sb + 1) & 1));           // (that buffer was last read in super-block sb - 1, before its barrier)
@@ -1165,6 +1187,18 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
             for (int64_t j = c0 + nsb * SCORE_SB; j < c1; ++j) {   // ragged tail of the split (< 16 cells): straight from global memory
                 const uint4 x = row_of(irow[j]);
                 const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+                if constexpr (NIB) {
+                    const uint4 *srow = reinterpret_cast<const uint4 *>(Lag) + ((int64_t)grp * n + j) * ROW + q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4 sp = srow[t * 8];
+                        const uint32_t sw[4] = {sp.x, sp.y, sp.z, sp.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            ai[t * 8 + e] += __umul24((w[t] >> (4 * e)) & 15u, (sw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int t = 0; t < TG; ++t) {
                     double2 l;
@@ -1183,10 +1217,19 @@ __global__ __launch_bounds__(SCORE_WAVES * 64) void k_moran_score_wg(
                 }
             }
             if (p < n_perm) {
+                if constexpr (NIB) {   // partial[group][split][perm][slot 64 t + 8 q + e]
+                    double2 *out = reinterpret_cast<double2 *>(partial + ((((int64_t)grp * n_splits + split) * n_perm + p) * 256 + q * 8));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2)
+                            out[t * 32 + e2] = make_double2((double)ai[t * 8 + 2 * e2], (double)ai[t * 8 + 2 * e2 + 1]);
+                } else {
                 // partial[group][split][perm][16 t + 2 q + e]
                 double2 *out = reinterpret_cast<double2 *>(partial) + (((int64_t)grp * n_splits + split) * n_perm + p) * ROW + q;
 #pragma unroll
                 for (int t = 0; t < TG; ++t) out[t * 8] = make_double2(acc[t][0], acc[t][1]);
+                }
             }
         }
     }
@@ -1325,6 +1368,160 @@ __global__ __launch_bounds__(256) void k_lag_u8(const long long *__restrict__ in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// r04: the 4-BIT source.  Count data is mostly small counts: a gene whose largest count is below 16 needs a nibble per
+// cell, and a gene with counts up to 255 is the sum of two such pseudo-genes, x = lo + 16 hi, whose statistics add exactly
+// (integer lattice: T = sum_j S_j x[inv(j)] = T_lo + 16 T_hi).  256 nibble SLOTS fit the 128-byte row the scoring kernel
+// gathers per (permutation, cell): slot s < G is the low nibble of gene s, slots G .. G + nw - 1 the high nibbles of the nw
+// genes that have one.  Used when that takes FEWER rows than 128 genes per uint8 row (the bench's 500 genes, 75 of them
+// with a count >= 16: 575 slots = 3 rows instead of 4 -- a quarter of the gathered bytes, which is what bounds the kernel).
+// Row layout: lane q of the 8 that share a row holds, in word t (0 .. 3) nibble e (0 .. 7), slot 64 t + 8 q + e; the
+// streamed operand is S (neighbour sums of the FULL gene, for both of its slots) as uint16 in slot order (512 bytes per
+// cell and group), so the lane's operands are again 16-byte LDS pieces (t, q) that are contiguous across q; products
+// (< 2^20) are added in int32 per task (15 x largest S x cells of a split < 2^31: checked on the host), then as doubles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_nib(const double *__restrict__ X, uint4 *__restrict__ out, int64_t n, int64_t G,
+                                                  int64_t NS, const int32_t *__restrict__ wide)
+{
+    const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (cell, q)
+    if (tt >= n * 8) return;
+    const int64_t cell = tt >> 3;
+    const int q = (int)(tt & 7), grp = blockIdx.y;
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t s0 = (int64_t)grp * 256 + t * 64 + q * 8;
+        if (s0 >= NS) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t s = s0 + e;
+            if (s >= NS) break;
+            const int64_t g = s < G ? s : (int64_t)wide[s - G];
+            const double x = X[(g >> 4) * n * SC_TILE + cell * SC_TILE + (g & 15)];
+            const uint32_t v = (uint32_t)(x >= 0.0 && x <= 255.0 ? x : 0.0);
+            o[t] |= (s < G ? (v & 15u) : (v >> 4)) << (4 * e);
+        }
+    }
+    out[((int64_t)grp * n + cell) * 8 + q] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// neighbour sums of every slot (uint16, slot order), cells in the graph's processing order like k_lag_u8
+__global__ __launch_bounds__(256) void k_lag_nib(const long long *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                 const uint4 *__restrict__ nib, const int32_t *__restrict__ order, int64_t n,
+                                                 uint4 *__restrict__ S16, int chunks)
+{
+    const int grp = blockIdx.y;
+    const int64_t per_xcd = (int64_t)(gridDim.x >> 3);
+    const int64_t chunk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // gridDim.x is a multiple of 8
+    if (chunk >= chunks) return;
+    const int q = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const uint4 *Xg = nib + (int64_t)grp * n * 8;
+    const int64_t p0 = chunk * LAG8_CELLS_PER_BLOCK;
+    for (int it = 0; it < LAG8_CELLS_PER_BLOCK / 32; ++it) {
+        const int64_t pos = p0 + it * 32 + row;
+        if (pos >= n) break;
+        const int64_t cell = order ? order[pos] : pos;
+        uint32_t acc[4][4];   // [word t][pair k]: 16-bit sums of nibbles e = 2 k (low half) and 2 k + 1 (high half)
+        uint32_t ev[4] = {0u, 0u, 0u, 0u}, od[4] = {0u, 0u, 0u, 0u};   // byte sums of the even / odd nibbles (<= 16 neighbours x 15)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[t][k] = 0u;
+        int pending = 0;
+        auto flush = [&]() {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[t][k] += ((ev[t] >> (8 * k)) & 0xffu) | (((od[t] >> (8 * k)) & 0xffu) << 16);
+                ev[t] = od[t] = 0u;
+            }
+            pending = 0;
+        };
+        for (long long e = indptr[cell]; e < indptr[cell + 1]; ++e) {
+            const uint4 v = Xg[(int64_t)indices[e] * 8 + q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ev[t] += w[t] & 0x0f0f0f0fu; od[t] += (w[t] >> 4) & 0x0f0f0f0fu; }
+            if (++pending == 16) flush();
+        }
+        flush();
+        uint4 *dst = S16 + ((int64_t)grp * n + cell) * 32 + q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t * 8] = make_uint4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+}
+
+// S of a gene with a high nibble = S_lo + 16 S_hi, for BOTH of its slots
+__global__ __launch_bounds__(256) void k_nib_fixup(uint16_t *__restrict__ S16, int64_t n, int64_t G, int nw,
+                                                   const int32_t *__restrict__ wide)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nw) return;
+    const int64_t cell = t / nw;
+    const int j = (int)(t - cell * nw);
+    const int64_t sl = wide[j], sh = G + j;
+    uint16_t *a = S16 + ((sl >> 8) * n + cell) * 256 + (sl & 255), *b = S16 + ((sh >> 8) * n + cell) * 256 + (sh & 255);
+    const uint32_t s = (uint32_t)*a + 16u * (uint32_t)*b;
+    *a = (uint16_t)s;
+    *b = (uint16_t)s;
+}
+
+// per slot and chunk of cells: sum nibble x S and sum S (integers, exact in fp64)
+__global__ __launch_bounds__(256) void k_nib_colsum(const uint8_t *__restrict__ nib, const uint16_t *__restrict__ S16, int64_t n,
+                                                    double *__restrict__ partT, double *__restrict__ partS, int chunks)
+{
+    const int grp = blockIdx.y, chunk = blockIdx.x, s = threadIdx.x;
+    const int q = (s & 63) >> 3, t = s >> 6, e = s & 7;
+    const int64_t c0 = (int64_t)chunk * LAG8_CELLS_PER_BLOCK, c1 = c0 + LAG8_CELLS_PER_BLOCK < n ? c0 + LAG8_CELLS_PER_BLOCK : n;
+    unsigned long long T = 0, SS = 0;
+    for (int64_t cell = c0; cell < c1; ++cell) {
+        const uint32_t S = S16[((int64_t)grp * n + cell) * 256 + s];
+        const uint32_t by = nib[((int64_t)grp * n + cell) * 128 + q * 16 + t * 4 + (e >> 1)];
+        const uint32_t v = (e & 1) ? (by >> 4) : (by & 15u);
+        T += (unsigned long long)v * S;
+        SS += S;
+    }
+    partT[((int64_t)grp * chunks + chunk) * 256 + s] = (double)T;
+    partS[((int64_t)grp * chunks + chunk) * 256 + s] = (double)SS;
+}
+
+// per gene: T_obs = sum x S = T[lo] + 16 T[hi], sum S (chunks in order)
+__global__ void k_nib_colsum_final(const double *__restrict__ partT, const double *__restrict__ partS, int chunks, int64_t G,
+                                   const int32_t *__restrict__ hi_slot, double *__restrict__ inum, double *__restrict__ slag)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int64_t sh = hi_slot[g];
+    double T = 0.0, Th = 0.0, S = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        T += partT[((g >> 8) * chunks + c) * 256 + (g & 255)];
+        S += partS[((g >> 8) * chunks + c) * 256 + (g & 255)];
+        if (sh >= 0) Th += partT[((sh >> 8) * chunks + c) * 256 + (sh & 255)];
+    }
+    inum[g] = T + 16.0 * Th;
+    slag[g] = S;
+}
+
+// sims / raw of the nibble form: the sums of a gene's slot(s) over the splits (ascending), T = T[lo] + 16 T[hi]
+__global__ __launch_bounds__(256) void k_moran_finalize_nib(const double *__restrict__ partial, const double *__restrict__ seff,
+                                                            const double *__restrict__ corr, const int32_t *__restrict__ hi_slot,
+                                                            double *__restrict__ sims, double *__restrict__ raw, int n_perm,
+                                                            int splits, int64_t n_genes, int64_t p0)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = t / n_genes, g = t - p * n_genes;
+    if (p >= n_perm) return;
+    const int64_t sh = hi_slot[g];
+    double lo = 0.0, hi = 0.0;
+    for (int k = 0; k < splits; ++k) {
+        lo += partial[((((g >> 8) * splits + k) * n_perm) + p) * 256 + (g & 255)];
+        if (sh >= 0) hi += partial[((((sh >> 8) * splits + k) * n_perm) + p) * 256 + (sh & 255)];
+    }
+    const double s = lo + 16.0 * hi;
+    raw[(p0 + p) * n_genes + g] = s;
+    sims[(p0 + p) * n_genes + g] = seff[g] * (s - corr[g]);
+}
+
 // Everything the permutation kernels need, from the loaded tiles and the active graph:
 //   value class + lattice decision per gene (one pass + one host sync), Z = X - centre, Lag = W Z (lattice genes: the
 //   unweighted neighbour sums of the raw counts), I, the per-gene finalisation constants, the narrow copy of the batch.
@@ -1419,12 +1616,58 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
     // an all-lattice uint8 batch (count data on a kNN graph): narrow copy first, then neighbour sums + both column sums
     // from the uint8 rows in one pass (k_lag_u8); no Z tiles at all (the lattice operand IS the raw value)
     const bool u8_prelude = n_perm > 0 && bits == 8 && lat_all && c->g_deg_max <= 257 && !getenv("SC_NO_U8_PRELUDE");
+    // ... or as NIBBLE slots (r04, "the 4-bit source" above) when that takes fewer gathered rows per (permutation, cell)
+    int64_t nw = 0;
+    uint32_t xmax_all = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        if (xmax[(size_t)g] >= 16u) ++nw;
+        if (xmax[(size_t)g] > xmax_all) xmax_all = xmax[(size_t)g];
+    }
+    const int64_t nib_slots = G + nw, nib_groups = ceil_div64(nib_slots, 256);
+    const bool nib = u8_prelude && c->source_bits_min <= 4 && nib_groups < ceil_div64(G, 128) &&
+                     15.0 * (double)xmax_all * (double)c->g_deg_max * (double)score_cells_per_split(n) < 2.0e9;
+    c->nib_groups = nib ? (int)nib_groups : 0;
     // ... with the neighbour sums kept as the 16-bit integers they are (r04): a quarter of the bytes k_lag_u8 writes in the
     // serial prelude and of the lag bytes every scoring launch streams (SC_LAG_FP64: the r03 form, for A/B runs)
-    const bool lag16 = u8_prelude && !getenv("SC_LAG_FP64");
+    const bool lag16 = u8_prelude && !nib && !getenv("SC_LAG_FP64");
     bool narrow_packed = false;   // the narrow copy of the batch exists already (built in front of the lag that reads it)
     c->lag_u16 = lag16;
-    if (u8_prelude) {
+    if (nib) {
+        c->lm_valid = false;   // (Lag is about to be rewritten)
+        bits = 4;
+        c->narrow_bits = 4;
+        c->lag_u16 = true;
+        // slot map: [Gpad] slot of the gene's high nibble (-1: none) | [nw] the genes that have one, ascending
+        std::vector<int32_t> map((size_t)Gpad + (size_t)(nw > 0 ? nw : 1), -1);
+        for (int64_t g = 0, j = 0; g < G; ++g)
+            if (xmax[(size_t)g] >= 16u) { map[(size_t)g] = (int32_t)(G + j); map[(size_t)Gpad + (size_t)j] = (int32_t)g; ++j; }
+        SC_TRY(c->nib_map.ensure(sizeof(int32_t) * map.size(), &c->mem));
+        SC_HIP(hipMemcpyAsync(c->nib_map.p, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, c->stream));
+        SC_HIP(hipStreamSynchronize(c->stream));   // (`map` is a local)
+        const int32_t *hi_slot = c->nib_map.as<int32_t>(), *wide = hi_slot + Gpad;
+        SC_TRY(c->X32.ensure(sizeof(uint4) * (size_t)nib_groups * n * 8, &c->mem));
+        SC_TRY(c->Lag.ensure(sizeof(uint4) * (size_t)nib_groups * n * 32, &c->mem));
+        hipLaunchKernelGGL(k_pack_nib, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)nib_groups), dim3(256), 0, c->stream,
+                           c->X.as<double>(), c->X32.as<uint4>(), n, G, nib_slots, wide);
+        const int chunks = (int)ceil_div64(n, LAG8_CELLS_PER_BLOCK);
+        const int32_t *order = (c->g_order_captured && c->g_n == n && c->g_order.p) ? c->g_order.as<int32_t>() : nullptr;
+        {
+            KernelTimerScope ts(c, SC_K_LAG);
+            hipLaunchKernelGGL(k_lag_nib, dim3((unsigned)align_up64(chunks, 8), (unsigned)nib_groups), dim3(256), 0, c->stream,
+                               c->g_indptr.as<long long>(), c->g_indices.as<int32_t>(), c->X32.as<uint4>(), order, n,
+                               c->Lag.as<uint4>(), chunks);
+            if (nw > 0)
+                hipLaunchKernelGGL(k_nib_fixup, dim3((unsigned)ceil_div64(n * nw, 256)), dim3(256), 0, c->stream,
+                                   c->Lag.as<uint16_t>(), n, G, (int)nw, wide);
+        }
+        SC_TRY(c->red_tmp.ensure(sizeof(double) * 2 * (size_t)nib_groups * chunks * 256, &c->mem));
+        double *partT = c->red_tmp.as<double>(), *partS = partT + (size_t)nib_groups * chunks * 256;
+        hipLaunchKernelGGL(k_nib_colsum, dim3((unsigned)chunks, (unsigned)nib_groups), dim3(256), 0, c->stream,
+                           c->X32.as<uint8_t>(), c->Lag.as<uint16_t>(), n, partT, partS, chunks);
+        hipLaunchKernelGGL(k_nib_colsum_final, dim3((unsigned)ceil_div64(G, 256)), dim3(256), 0, c->stream, partT, partS, chunks, G,
+                           hi_slot, c->g_Inum.as<double>(), c->g_slag.as<double>());
+        SC_HIP(hipGetLastError());
+    } else if (u8_prelude) {
         c->lm_valid = false;   // (Lag is about to be rewritten)
         SC_TRY(c->X32.ensure(sizeof(float) * (size_t)((T + 1) / 2) * n * 32, &c->mem));
         hipLaunchKernelGGL(k_pack_narrow<8>, dim3((unsigned)ceil_div64(n * 8, 256), (unsigned)ceil_div64(T, 8)), dim3(256), 0,
@@ -1477,10 +1720,11 @@ static int moran_prepare(sc_ctx *c, int64_t n_perm, bool allow_lattice)
         int64_t cps = 0;
         const int splits64 = pick_splits(n, 1, &cps);  // upper bound on the index-row kernel's split count
         const int64_t score_splits = ceil_div64(n, score_cells_per_split(n));
-        const size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
+        size_t narrow_rows = (size_t)score_splits * (size_t)align_up64(T * SC_TILE, 128);
+        if (nib && (size_t)score_splits * (size_t)nib_groups * 256 > narrow_rows) narrow_rows = (size_t)score_splits * (size_t)nib_groups * 256;
         const size_t wide_rows = (size_t)splits64 * SC_TILE;
         SC_TRY(c->partial.ensure(sizeof(double) * (size_t)n_perm * (narrow_rows > wide_rows ? narrow_rows : wide_rows), &c->mem));
-        if (bits < 64 && !u8_prelude && !narrow_packed) {
+        if (bits < 64 && bits > 4 && !u8_prelude && !narrow_packed) {
             // the gathered operand: the raw values in the narrowest type that holds every gene of the batch exactly
             const int64_t T32 = (T + 1) / 2;
             SC_TRY(c->X32.ensure(sizeof(float) * (size_t)T32 * n * 32, &c->mem));   // >= the uint16 / uint8 copies
@@ -1558,7 +1802,7 @@ static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int 
     // take the per-wavefront form -- same results (SC_SCORE_WG_MIN: development, to sweep the threshold)
     static const int wg_min = getenv("SC_SCORE_WG_MIN") ? atoi(getenv("SC_SCORE_WG_MIN")) : SCORE_WG_MIN_PERMS;
     const int last_task = cnt % (8 * SCORE_WAVES);
-    if (!private_lag && (last_task == 0 || last_task >= (BITS == 64 ? 6 * SCORE_WAVES : wg_min))) {
+    if (BITS == 4 || (!private_lag && (last_task == 0 || last_task >= (BITS == 64 ? 6 * SCORE_WAVES : wg_min)))) {
         const int64_t tasks = (int64_t)groups * splits * ((cnt + 8 * SCORE_WAVES - 1) / (8 * SCORE_WAVES));
         if (wgs > tasks) wgs = (int)tasks;
         // (r03 measured the grid rounded to whole rounds of tasks -- 1956 tasks are 13 rounds on 160 workgroups, 12 on 163,
@@ -1570,6 +1814,7 @@ static void launch_score(sc_ctx *c, int wgs, const uint4 *rows, int64_t p0, int 
                            splits, groups);
         return;
     }
+    if constexpr (BITS != 4)
     hipLaunchKernelGGL((k_moran_score<BITS, CB, BIG, L16>), dim3((unsigned)(wgs * (SCORE_WAVES / SCORE_PRIVATE_WAVES))),
                        dim3(SCORE_PRIVATE_WAVES * 64), 0, c->stream, rows,
                        c->Lag.as<double>(), (int64_t)c->e_n * SC_TILE, (int)c->e_tiles, c->g_meanc.as<double>(),
@@ -1592,8 +1837,8 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         const bool big = n >= ((int64_t)1 << 25);
         SC_REQUIRE(!big || bits == 64, SC_ERR_STATE, "internal: %lld cells need the 64-bit-address scoring kernel", (long long)n);
         if (invert_here) SC_TRY(invert_rows(c, p0, p1, c->stream));
-        const int GP = bits == 8 ? 128 : bits == 16 ? 64 : bits == 32 ? 32 : 16;
-        const int groups = (int)ceil_div64(T * SC_TILE, GP);
+        const int GP = bits == 4 ? 256 : bits == 8 ? 128 : bits == 16 ? 64 : bits == 32 ? 32 : 16;
+        const int groups = bits == 4 ? c->nib_groups : (int)ceil_div64(T * SC_TILE, GP);
         const int64_t cps = score_cells_per_split(n);
         const int splits = (int)ceil_div64(n, cps);
         // one workgroup per compute unit: all of them, or all but those left to a generator that runs beside us
@@ -1608,12 +1853,20 @@ static int moran_perm_range(sc_ctx *c, int64_t p0, int64_t p1, int bits, bool in
         {
             KernelTimerScope ts(c, SC_K_MORAN_PERM);
             // (8 cells per stage were measured for the narrow sources too: under the 128-VGPR cap of the 1024-thread form they spill)
-            if (bits == 8 && c->lag_u16) launch_score<8, 4, false, true>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            if (bits == 4) launch_score<4, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
+            else if (bits == 8 && c->lag_u16) launch_score<8, 4, false, true>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (bits == 8) launch_score<8, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (bits == 16) launch_score<16, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (bits == 32) launch_score<32, 4, false>(c, wgs, c->X32.as<uint4>(), p0, cnt, cps, splits, groups);
             else if (!big) launch_score<64, 8, false>(c, wgs, c->Z.as<uint4>(), p0, cnt, cps, splits, groups);
             else launch_score<64, 8, true>(c, wgs, c->Z.as<uint4>(), p0, cnt, cps, splits, groups);
+        }
+        if (bits == 4) {
+            hipLaunchKernelGGL(k_moran_finalize_nib, dim3((unsigned)ceil_div64((int64_t)cnt * G, 256)), dim3(256), 0, c->stream,
+                               c->partial.as<double>(), c->g_seff.as<double>(), c->g_corr.as<double>(), c->nib_map.as<int32_t>(),
+                               c->sims.as<double>(), c->sims_raw.as<double>(), cnt, splits, G, p0);
+            SC_HIP(hipGetLastError());
+            return SC_OK;
         }
         const dim3 fgrid((unsigned)ceil_div64((int64_t)cnt * GP, 256), (unsigned)groups);
         auto fin = bits == 8 ? k_moran_finalize_groups<128> : bits == 16 ? k_moran_finalize_groups<64>

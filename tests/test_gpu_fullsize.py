@@ -445,7 +445,7 @@ def test_config3_one_ranks_full_share_5m_cells_250_genes_p1000(oracle):
         out = ctx.moran_seeded(w, P)
         par, seq, fallbacks, prepared, chained = ctx.permgen_stats()
         assert (par, seq, fallbacks) == (1, 0, 0) and prepared > 5 * chained > 0
-        assert ctx.moran_source_bits() == 8 and ctx.moran_lag_bits() == 16
+        assert ctx.moran_source_bits() == 8 and ctx.moran_lag_bits() == 16 and ctx.moran_row_groups() == 2
         assert ctx.device_mem() < 150 * 2**30
         wh = _lib.rng_state_words(np.random.default_rng(8))
         last = None

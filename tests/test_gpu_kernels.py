@@ -433,13 +433,16 @@ def test_moran_source_widths_agree(ctx, oracle, G):
     ctx.knn(coords, k, fetch=False)
     ctx.graph_from_knn(1.0 / k)
     out = {}
+    # r04: 4-bit slots (a count < 16 one nibble, a count < 256 two: x = lo + 16 hi) are used when they take fewer rows
+    n_wide = int((np.asarray(X).max(axis=0) >= 16).sum())
+    nib_expected = -(-(G + n_wide) // 256) < -(-G // 128)
     try:
-        for bits in (8, 16, 32, 64):
+        for bits in (4, 8, 16, 32, 64):
             ctx.set_moran_source_bits(bits)
             ctx.set_expression(X, np.arange(G))
             w = rng_state_words(np.random.default_rng(3))
             out[bits] = ctx.moran_seeded(w, P)
-            assert ctx.moran_source_bits() == bits
+            assert ctx.moran_source_bits() == (bits if bits > 4 or nib_expected else 8), (bits, G, n_wide)
         ctx.set_moran_source_bits(8)
         for Xd, want in ((X + np.float32(250.0), 16),              # counts beyond 255: no uint8 copy
                          (X + np.float32(0.5), 32),                # fractional float32 values: no uint16 copy
@@ -471,9 +474,9 @@ def test_moran_source_widths_agree(ctx, oracle, G):
         for key in ("I", "sims", "count_ge"):
             np.testing.assert_array_equal(hard[key], hard64[key], err_msg=key)
     finally:
-        ctx.set_moran_source_bits(8)
+        ctx.set_moran_source_bits(8)      # the default
     assert tab["lattice"].all()
-    for bits in (16, 32, 64):
+    for bits in (4, 16, 32, 64):
         for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
             np.testing.assert_array_equal(out[8][key], out[bits][key], err_msg=f"{key} uint8 vs {bits}")   # bit-identical
     for bits in (8, 16):
@@ -482,6 +485,50 @@ def test_moran_source_widths_agree(ctx, oracle, G):
         assert_counts_match(out[bits]["count_ge"], tab)
     with pytest.raises(ValueError):
         ctx.set_moran_source_bits(12)
+
+
+@pytest.mark.parametrize("n,G,P,wide_every", [(3000, 300, 37, 0), (5000, 523, 130, 7), (2049, 131, 9, 3), (70001, 260, 150, 5)])
+def test_moran_four_bit_source_equals_uint8_and_the_oracle(ctx, oracle, n, G, P, wide_every):
+    """r04, the 4-bit source (opt-in, sc_ctx_set_moran_source_bits(4)) on its own: counts below 16 as one nibble slot, genes with larger counts (every
+    `wide_every`-th, up to 255) as two, in every combination of group fill -- statistics, counts and sums EQUAL to the
+    uint8 source's (both are exact integer arithmetic) and the oracle's; sc_moran on a resident table and the pipelined
+    sc_moran_seeded (chunks shorter than 24 permutations included: the nibble form has no per-wavefront fallback)."""
+    from spatialcore_amd._lib import rng_state_words
+
+    k = 6
+    rng = np.random.default_rng(n + G)
+    coords = rng.uniform(0, np.sqrt(n) * 10, (n, 2))
+    X = rng.poisson(1.2, (n, G)).astype(np.float32)
+    X = np.minimum(X, 15)
+    if wide_every:
+        X[:, ::wide_every] = rng.integers(0, 256, (n, X[:, ::wide_every].shape[1]))
+        X[0, 0] = 255.0
+    n_wide = int((X.max(axis=0) >= 16).sum())
+    assert -(-(G + n_wide) // 256) < -(-G // 128)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    runs = {}
+    try:
+        for bits in (4, 8):
+            ctx.set_moran_source_bits(bits)
+            ctx.set_expression(X, np.arange(G))
+            runs[bits] = ctx.moran_seeded(rng_state_words(np.random.default_rng(5)), P)
+            assert ctx.moran_source_bits() == bits and ctx.moran_lag_bits() == 16
+            if bits == 4:
+                assert ctx.moran_row_groups() == -(-(G + n_wide) // 256)
+                two_step = ctx.moran(P)                     # the resident (inverse) table, scored again by sc_moran
+                for key in ("I", "sims", "count_ge"):
+                    np.testing.assert_array_equal(two_step[key], runs[4][key], err_msg=key)
+    finally:
+        ctx.set_moran_source_bits(8)
+    for key in ("I", "sims", "count_ge", "sim_sum", "sim_sumsq"):
+        np.testing.assert_array_equal(runs[4][key], runs[8][key], err_msg=key)
+    cols = [0, 1, G // 2, G - 1] + ([wide_every, 2 * wide_every] if wide_every else [])
+    tab = oracle.morans_i_reference_table(coords, X[:, cols], list(range(len(cols))), k, P, seed=5)
+    np.testing.assert_allclose(runs[4]["I"][cols], tab["I"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(runs[4]["sims"][:, cols], tab["sims"], rtol=1e-9, atol=1e-13)
+    assert tab["lattice"].all()
+    np.testing.assert_array_equal(runs[4]["count_ge"][cols], tab["count_ge"])
 
 
 @pytest.mark.parametrize("graph", ["knn", "radius"])
