@@ -66,7 +66,13 @@ def main() -> None:
     wtot = sum(write.get(k, [0, 0.0])[1] for k in fk)
     f_kib = ftot / nd
     w_kib = wtot / max(wd, 1)
-    hbm = (f_kib * (2.0 if double_fetch else 1.0) + w_kib) * 1024.0
+    # r04: the uint8 form streams its lag operand as 4-byte words (16-bit neighbour sums, 256 B per cell and 128-gene group);
+    # 4-byte-per-lane loads are counted in full, so that part of FETCH_SIZE is NOT doubled (SC_LAG4B_BYTES: its bytes per
+    # launch; default = cells x 256 B x ceil(genes / 128) when a 16-bit-lag form of the kernel was measured)
+    lag4 = 0.0
+    if any(", true>" in k for k in fk):
+        lag4 = float(os.environ.get("SC_LAG4B_BYTES", cells * 256.0 * -(-genes // 128)))
+    hbm = (f_kib * (2.0 if double_fetch else 1.0) + w_kib) * 1024.0 - (lag4 if double_fetch else 0.0)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from spatialcore_amd import _lib
 
@@ -81,11 +87,13 @@ def main() -> None:
         "FETCH_SIZE_KiB_per_launch": f_kib,
         "WRITE_SIZE_KiB_per_launch": w_kib,
         "fetch_doubled": double_fetch,
+        "four_byte_lag_bytes_not_doubled": lag4,
         "hbm_bytes_per_launch": hbm,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of "
                   "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-public-api --no-alone`, aggregated by scripts/pmc_traffic.py; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B-per-lane "
-                  "reads; every load of this kernel is 16 B per lane); the counters are L2 memory-side requests, "
+                  "reads; every load of this kernel is 16 B per lane except the 16-bit lag words of the uint8 form, whose "
+                  "bytes are subtracted once from the doubled figure); the counters are L2 memory-side requests, "
                   "Infinity-Cache hits included",
     }
     with open(os.path.join(out, f"{kernel}_pmc_traffic.json"), "w") as f:
