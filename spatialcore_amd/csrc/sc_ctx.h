@@ -227,7 +227,7 @@ void sc_perm_pipe_abort(sc_ctx *c);    // drain and drop c->pipe (no results)
 bool permgen_is_block_parallel(const sc_ctx *c, int64_t n);  // which scan form a job of length n takes
 int permgen_begin(sc_ctx *c, const uint64_t *state6, int64_t n, int64_t n_perm, PermJob *job, hipStream_t s);
 int permgen_scan_chunk(sc_ctx *c, PermJob *job, int64_t p1, hipStream_t s, hipStream_t post, hipEvent_t done);
-int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse);
+int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse, int pw_req);
 bool permgen_can_swap_inverse(int64_t n);
 int sc_perm_forward_ensure(sc_ctx *c);  // materialise c->perm from c->inv after a pipeline that only made the inverse
 int permgen_finish(sc_ctx *c, PermJob *job, uint64_t *state6);

@@ -2035,7 +2035,8 @@ static int pipe_generate(sc_ctx *c, PermPipe &pp, int64_t k)
     SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
     SC_TRY(permgen_scan_chunk(c, &pp.job, pp.bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
     SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
-    SC_TRY(permgen_swap_chunk(c, &pp.job, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw, pp.table == 1));
+    // (two permutations per swap workgroup while the chain still runs: workgroups of the preparation kernels' own size)
+    SC_TRY(permgen_swap_chunk(c, &pp.job, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw, pp.table == 1, k >= chunks - 3 ? 1 : 2));
     if (pp.table == 2) SC_TRY(invert_rows(c, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw));
     SC_HIP(hipEventRecord(swapped, sw));
     pp.enqueued = k + 1;

@@ -278,9 +278,86 @@ __device__ unsigned long long g_phi_prof[32 + 2 * 128];   // development: see k_
                                                           // [32 ..): log of (unit | first unit of the launch << 32, clocks waited) of long waits
 #endif
 
+__device__ __forceinline__ uint32_t select64(uint64_t x, uint32_t r)  // position of the set bit of rank r < popc(x)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(sc_shr64(x, pos) & ((1ull << sh) - 1ull));   // (sh is a literal: a constant mask)
+        if (r >= c) { r -= c; pos += sh; }
+    }
+    return pos;
+}
+
 struct BlockShared {
     uint32_t wsum[2][SCAN_THREADS / 64];   // per wavefront: accept count | (recomputed something last round) << 31; by round parity
 };
+
+// r04: the END of a permutation, solved draw by draw (k_chain's computed blocks).
+// The fixed point below grows its exact prefix band by band, and through the last few hundred steps of a permutation --
+// thresholds of a few hundred, where every accepted draw before a thread changes what the thread does -- by two or three
+// THREADS a round: 8 of the ~16 rounds of the block in which a permutation ends (CPU restatement of the rounds: the
+// front's thread by round reads 924, 926, 937, 939, 940, 943, 945 of 1024; scripts/fixed_point_rounds_sim.py).  Once the
+// exact prefix has reached TAIL_I steps before the permutation's end, wavefront 0 takes over from there with one LANE per
+// draw: 64 draws at a time, accept set = fixed point of "v <= i - (accepted lanes below)" by ballot (2-3 iterations, ~50
+// clocks each), cut at the draw that halves the mask or completes the permutation.  It runs to the end of the thread in
+// which the permutation ends; those threads take their accept bits and entering counts from LDS and are never stale
+// again; the threads behind start a permutation with i = M, where a round settles them.
+#ifndef TAIL_I
+#define TAIL_I 1024                    // steps before the permutation's end at which the lanes take over
+#endif
+#define TAIL_THREADS (TAIL_I / 4 + 32) // threads' worth of staged draws: the last TAIL_I steps take ~1.37 TAIL_I draws (sd ~ sqrt)
+struct TailShared {
+    uint32_t fst[2][SCAN_THREADS / 64];            // per wavefront: (first stale thread << 16 | min(steps left there, 0xffff)), or ~0; by round parity
+    uint32_t u[TAIL_THREADS * SCAN_D];             // the staged draws
+    uint8_t acc[TAIL_THREADS * SCAN_D];            // their accept decisions
+    uint32_t cin[TAIL_THREADS];                    // entering count of each solved thread, relative to the front's
+    uint32_t nsolved;                              // threads solved
+    uint32_t open;                                 // this block may still call the lanes (kept here: k_chain has no register to spare)
+};
+
+// wavefront 0: draws tu[0 .. nq) entered with i steps left in the permutation (mask = mask_of(i)); returns the number of
+// draws decided (a multiple of SCAN_D: through the thread in which the permutation ends, or all nq)
+__device__ __forceinline__ uint32_t tail_solve(TailShared &ts, uint32_t nq, uint32_t i, uint32_t M, uint32_t top_mask)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t mask = mask_of(i), c = 0, q = 0;
+    bool wrapped = false;
+    while (q < nq) {
+        uint32_t len = nq - q < 64u ? nq - q : 64u;
+        if (wrapped) {                       // finish the thread in which the permutation ended, then stop
+            const uint32_t restd = (SCAN_D - (q & (SCAN_D - 1))) & (SCAN_D - 1);
+            if (restd == 0) break;
+            len = restd;
+        }
+        const bool in = lane < len;
+        const uint32_t v = in ? (ts.u[q + lane] & mask) : 0xffffffffu;
+        unsigned long long A = __ballot(in && v <= i);          // every threshold at its upper bound
+        for (int it = 0; it < 66; ++it) {                        // (the exact prefix grows by a lane an iteration at least)
+            const uint32_t pre = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(A >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)A, 0u));
+            const unsigned long long A2 = __ballot(in && pre <= i && v <= i - pre);
+            if (A2 == A) break;
+            A = A2;
+        }
+        // the accepts that change the mask (or complete the permutation): i falls to mask >> 1 after i - (mask >> 1) of them
+        const uint32_t half = mask >> 1, nb = i - half;
+        uint32_t T = (uint32_t)__popcll(A);
+        if (T >= nb) {
+            len = select64(A, nb - 1u) + 1u;
+            A &= sc_low_mask64(len);
+            T = nb;
+        }
+        if (lane < len) {
+            ts.acc[q + lane] = (uint8_t)((A >> lane) & 1ull);
+            if (((q + lane) & (SCAN_D - 1)) == 0)
+                ts.cin[(q + lane) / SCAN_D] = c + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(A >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)A, 0u));
+        }
+        c += T; i -= T; q += len;
+        if (i == 0) { i = M; mask = top_mask; wrapped = true; }
+        else if (i <= half) mask = half;
+    }
+    return q;
+}
 
 // inclusive prefix sum inside each row of 16 lanes
 __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t x)
@@ -303,10 +380,11 @@ __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t x)
 // of bookkeeping per wavefront and round -- 16 wavefronts on one CU make a round throughput-bound, ~2.5 us; measured
 // 3.6 rounds for an ordinary computed block, 13 for the block in which a permutation ends.)
 // Returns 1 if the iteration cap was hit (cannot happen: the prefix grows by at least one thread a round).
+template <bool TAIL = false>
 __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], uint64_t S_block,
                                                  uint32_t rem_block, uint32_t M, uint32_t top_mask, uint64_t total_steps, BlockShared &sh,
                                                  uint32_t &parity, ScanRes &r, uint32_t &excl, uint32_t &total_cnt,
-                                                 int *rounds_out = nullptr)
+                                                 int *rounds_out = nullptr, TailShared *ts = nullptr)
 {
     // rem_block = M - S_block % M, the steps left in the current permutation (callers carry it along: a
     // 64-bit modulo per block by every wavefront costs more than a fifth of the block)
@@ -326,11 +404,18 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
 #endif
     excl = 0; total_cnt = 0;
     uint32_t recomputed = 1u;
+    // TAIL: only where the permutation that ends is not the job's last (its end is the job's `limit`, which the lanes do not know)
+    if (TAIL) {
+        if (tau == 0) ts->open = (left > (uint64_t)rem_block && rem_block <= SCAN_BLOCK) ? 1u : 0u;
+        if (lane == 0) ts->fst[parity][wave] = 0xffffffffu;   // (no front before the first round)
+    }
     for (int iter = 0;; ++iter) {
         const uint32_t incl = wave_inclusive_scan(r.cnt);
         if (lane == 63) sh.wsum[parity][wave] = incl | (recomputed << 31);
         __syncthreads();
         const uint32_t mine = lane < NW ? sh.wsum[parity][lane] : 0u;
+        const bool tail_open = TAIL && ts->open != 0u;
+        const uint32_t fst = (tail_open && lane < NW) ? ts->fst[parity][lane] : 0xffffffffu;
         parity ^= 1u;   // the other buffer is rewritten only after the next barrier, i.e. after everybody has read this one
         const bool anybody = __any((int)(mine >> 31));
         const uint32_t run = row16_inclusive_scan(mine & 0x7fffffffu);
@@ -341,8 +426,52 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
             if (rounds_out) *rounds_out = iter + 1;
             return 0;
         }
-        const bool stale = !scan_still_valid(r, excl, M, limit);
-        recomputed = __any(stale) ? 1u : 0u;
+        bool pinned_now = false;
+        if (tail_open) {
+            // The front: the first stale thread of the previous round.  Nobody in front of it was stale, so its entering
+            // count was exact then and still is (and it has been recomputed with it since).
+            const unsigned long long has = __ballot(fst != 0xffffffffu);
+            if (has) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fst, (int)__builtin_ctzll(has));
+                const uint32_t s = f >> 16, i_front = f & 0xffffu;
+                if (i_front <= TAIL_I) {   // (uniform) -- steps left in the permutation the BLOCK was entered in
+                    const uint32_t nthr = SCAN_THREADS - s < TAIL_THREADS ? SCAN_THREADS - s : TAIL_THREADS;
+                    if (tau >= s && tau < s + nthr) {
+#pragma unroll
+                        for (int k = 0; k < SCAN_D; ++k) ts->u[(tau - s) * SCAN_D + k] = u[k];
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        const uint32_t nq = tail_solve(*ts, nthr * SCAN_D, i_front, M, top_mask);
+                        if (lane == 0) { ts->nsolved = nq / SCAN_D; ts->open = 0u; }   // (everybody has read `open` in front of the barrier above)
+                    }
+                    __syncthreads();
+                    const uint32_t ns = ts->nsolved;
+                    if (tau >= s && tau < s + ns) {
+                        bits_t b = 0;
+#pragma unroll
+                        for (int k = 0; k < SCAN_D; ++k) b |= (bits_t)ts->acc[(tau - s) * SCAN_D + k] << k;
+                        r.bits = b; r.cnt = (uint32_t)__popcll((unsigned long long)b); r.gap = 0; r.fast = 0; r.end = 0;
+                        r.c_used = (rem_block - i_front) + ts->cin[tau - s];   // exact: valid from the next round on, and for good
+                        pinned_now = true;
+                    }
+                }
+            }
+        }
+        const bool stale = !pinned_now && !scan_still_valid(r, excl, M, limit);
+        recomputed = (__any(stale) || __any(pinned_now)) ? 1u : 0u;
+        if (tail_open) {   // my wavefront's first stale thread | steps left there, for the next round (that buffer's readers are done)
+            const unsigned long long sm = __ballot(stale);
+            uint32_t my_front = 0xffffffffu;
+            if (sm) {
+                const int fl = (int)__builtin_ctzll(sm);
+                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)excl, fl);
+                // steps left at that thread in the permutation the block was entered in (beyond its end: not our business)
+                const uint32_t il = ce < rem_block ? rem_block - ce : 0xffffu;
+                my_front = (((uint32_t)wave * 64u + (uint32_t)fl) << 16) | (il < 0xffffu ? il : 0xffffu);
+            }
+            if (lane == 0) ts->fst[parity][wave] = my_front;
+        }
 #ifdef PHI_PROFILE
         if (rounds_out && lane == 0) {   // wavefronts that recompute, by round (1, 2, 3, later)
             if (recomputed) atomicAdd(&g_phi_prof[26 + (iter < 3 ? iter : 3)], 1ull);
@@ -552,17 +681,6 @@ __device__ static unsigned long long phi_expect(unsigned long long S, double dq,
     return S < total ? S : total;
 }
 
-__device__ __forceinline__ uint32_t select64(uint64_t x, uint32_t r)  // position of the set bit of rank r < popc(x)
-{
-    uint32_t pos = 0;
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        const uint32_t c = (uint32_t)__popcll(sc_shr64(x, pos) & ((1ull << sh) - 1ull));   // (sh is a literal: a constant mask)
-        if (r >= c) { r -= c; pos += sh; }
-    }
-    return pos;
-}
-
 // One wavefront builds the surviving-increment bitset of one side (lane l holds bits [256 l, 256 l + 256)).
 __device__ __forceinline__ void phi_tbuild(const uint16_t *ev, uint32_t nev, uint32_t w, unsigned long long *out)
 {
@@ -721,6 +839,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_phi_events(const uint32_t *__r
 #define PHI_SEG_MAX 16        // blocks per segment at most (segments are cut at multiples of this inside a unit)
 #endif
 #define PHI_COMPOSE_WGS (PHI_UNIT / 2)   // workgroups of k_phi_compose: one per multi-block segment, the others leave at once
+#ifndef PHI_TAIL_PLUS
+#define PHI_TAIL_PLUS
+#endif
+#ifndef PHI_TAIL
+#define PHI_TAIL false        // r04 NEGATIVE RESULT, kept as a development build (-DPHI_TAIL=true): the end of a permutation inside a
+                              // computed block by lanes (tail_solve, see BlockShared) -- rounds 16.1 -> 10.2, clocks 67.9 k -> 76.2 k
+#endif
+#define PHI_TAIL_LDS (0 PHI_TAIL_PLUS)   // (the preprocessor cannot test `true`: build the variant with -DPHI_TAIL=true -DPHI_TAIL_PLUS=+1)
 #define PHI_NS 6              // segments whose tables the chain stages in LDS at once (a run of prepared blocks)
 #define PHI_STAGE_PIECES 64   // 16-byte pieces per side the chain stages: entry gaps up to 8192 (beyond: global memory)
 
@@ -1462,6 +1588,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
                                                         uint32_t launch_id)
 {
     __shared__ BlockShared sh;
+#if PHI_TAIL_LDS
+    __shared__ TailShared tsh;
+    TailShared *const tshp = &tsh;
+#else
+    TailShared *const tshp = nullptr;
+#endif
     __shared__ uint32_t shReady;
     __shared__ __align__(8) PhiSeg sg[PHI_UNIT];
     __shared__ uint16_t nxt[PHI_UNIT + 2];  // first block >= i (relative to b0) the chain computes itself
@@ -1723,7 +1855,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
 #ifdef PHI_PROFILE
         const uint32_t pf_rem = rem;
         int pf_rounds = 0;
-        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, &pf_rounds) > 0) { failed = 1; break; }
+        if (block_fixed_point<PHI_TAIL>(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, &pf_rounds, tshp) > 0) { failed = 1; break; }
         if (tau == 0) {   // computed blocks by the steps left in their permutation: count, clocks of the fixed point, rounds
             const int cls = pf_rem > 98304u ? 0 : pf_rem > 49152u ? 1 : pf_rem > 24576u ? 2 : pf_rem > 12288u ? 3 : 4;
             atomicAdd(&g_phi_prof[cls * 4], 1ull);
@@ -1731,7 +1863,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chain(const uint32_t *__restri
             atomicAdd(&g_phi_prof[cls * 4 + 2], (unsigned long long)pf_rounds);
         }
 #else
-        if (block_fixed_point(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt) > 0) { failed = 1; break; }
+        if (block_fixed_point<PHI_TAIL>(u, S, rem, M, top_mask, total_steps, sh, parity, r, excl, total_cnt, nullptr, tshp) > 0) { failed = 1; break; }
 #endif
         const uint64_t bx = b0 + x;
         acc_bits[bx * SCAN_THREADS + tau] = r.bits;
@@ -1895,48 +2027,65 @@ __global__ __launch_bounds__(64) void k_apply_swaps(const int32_t *__restrict__ 
 // fill of the row beyond slot 0.  -DSW_NO_PREFETCH: the r02 form (A/B builds).
 #define SW_RING 2048   // partners of steps [done, done + <= 1536) live here
 
-template <bool ASC>
-__global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
-                                                         int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
+
+// r04: PW permutations per workgroup (PW x SW_T threads, each SW_T-thread half runs its own permutation with its own LDS
+// structures, the barriers are shared: a round is latency-bound, two of them in lockstep cost what one costs).  Why: a
+// swap workgroup lives ~10 ms, and 128 of them with 8 wavefronts each, spread over the CUs the scoring kernel leaves,
+// fragment the wavefront slots that the generator's 1024-thread preparation workgroups need sixteen of on one CU (4.3 of
+// the chain's 7-9 ms waits).  With PW = 2 a chunk is 64 workgroups of the preparation kernels' own size.
+template <bool ASC, int PW>
+__global__ __launch_bounds__(SW_T * PW) void k_apply_swaps_wg(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
+                                                              int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
 {
-    __shared__ uint32_t hkey[SW_HASH], hmin[SW_HASH];
-    __shared__ uint32_t first_conf[2];
+    __shared__ uint32_t hkey_[PW][SW_HASH], hmin_[PW][SW_HASH];
+    __shared__ uint32_t first_conf_[PW][2];
+    __shared__ uint32_t act[2];
 #ifndef SW_NO_PREFETCH
-    __shared__ int32_t jring[SW_RING];
+    __shared__ int32_t jring_[PW][SW_RING];
 #endif
-    const int64_t p = p0 + blockIdx.x;
-    if (p >= n_perm) return;
-    const uint32_t l = threadIdx.x;
+    const uint32_t half = PW > 1 ? threadIdx.x / SW_T : 0u;
+    const uint32_t l = PW > 1 ? threadIdx.x % SW_T : threadIdx.x;
+    uint32_t *hkey = hkey_[half], *hmin = hmin_[half], *first_conf = first_conf_[half];
+#ifndef SW_NO_PREFETCH
+    int32_t *jring = jring_[half];
+#endif
+    const int64_t p = p0 + (int64_t)blockIdx.x * PW + half;
+    const bool exists = p < n_perm;          // (an odd chunk: the last workgroup's second half has nothing to do but meet the barriers)
     const uint32_t M = n - 1;
-    int32_t *A = perm + p * pstride;
-    const int32_t *Jp = J + p * (int64_t)M;
+    int32_t *A = perm + (exists ? p : p0) * pstride;
+    const int32_t *Jp = J + (exists ? p : p0) * (int64_t)M;
 #ifndef SW_NO_PREFETCH
     // step k = 0 .. M - 1 of the processing order: i = 1 + k (ascending) or n - 1 - k; its partner is Jp[M - i]
     auto step_i = [&](int64_t k) -> int64_t { return ASC ? 1 + k : (int64_t)n - 1 - k; };
-    if (!ASC) { for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x; }
-    else if (l == 0) A[0] = 0;
-    for (int r = 0; r < 2; ++r) {   // partners of the first 2 SW_T steps
-        const int64_t k = (int64_t)r * SW_T + l;
-        jring[k & (SW_RING - 1)] = k < (int64_t)M ? Jp[(int64_t)M - step_i(k)] : -1;
+    if (exists) {
+        if (!ASC) { for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x; }
+        else if (l == 0) A[0] = 0;
+        for (int r = 0; r < 2; ++r) {   // partners of the first 2 SW_T steps
+            const int64_t k = (int64_t)r * SW_T + l;
+            jring[k & (SW_RING - 1)] = k < (int64_t)M ? Jp[(int64_t)M - step_i(k)] : -1;
+        }
     }
     int64_t filled = 2 * SW_T;      // partners of steps [done, filled) are in the ring
 #else
-    for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x;
+    if (exists) for (uint32_t x = l; x < n; x += SW_T) A[x] = (int32_t)x;
 #endif
+    int64_t i_cur = ASC ? 1 : (int64_t)n - 1;  // first step of the round
+    if (!exists) i_cur = ASC ? (int64_t)n : 0; // (done)
     if (l < 2) first_conf[l] = SW_T;
+    if (l == 0) act[half] = (ASC ? i_cur <= (int64_t)n - 1 : i_cur >= 1) ? 1u : 0u;
+    if (PW == 1 && l == 0) act[1] = 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int64_t i_cur = ASC ? 1 : (int64_t)n - 1;  // first step of the round
     uint32_t round = 0;
-    while (ASC ? i_cur <= (int64_t)n - 1 : i_cur >= 1) {
+    while (act[0] | act[1]) {       // (uniform: the words are rewritten in front of the round's last barrier)
         const int64_t i = ASC ? i_cur + l : i_cur - l;
-        const bool valid = ASC ? i <= (int64_t)n - 1 : i >= 1;
+        const bool valid = exists && (ASC ? (i_cur <= (int64_t)n - 1 && i <= (int64_t)n - 1) : (i_cur >= 1 && i >= 1));
 #ifndef SW_NO_PREFETCH
         const int64_t done = ASC ? i_cur - 1 : (int64_t)n - 1 - i_cur;   // steps applied so far
         int32_t j = valid ? jring[(done + l) & (SW_RING - 1)] : -1;
         // the ring's next SW_T partners are on their way while this round works (stored at its end)
-        const bool top_up = filled - done <= 2 * SW_T;
+        const bool top_up = exists && filled - done <= 2 * SW_T;
         const int64_t kf = filled + l;
         int32_t j_next = -1;
         if (top_up && kf < (int64_t)M) j_next = Jp[(int64_t)M - step_i(kf)];
@@ -1979,21 +2128,203 @@ __global__ __launch_bounds__(SW_T) void k_apply_swaps_wg(const int32_t *__restri
         if (l == 0) first_conf[(round + 1) & 1] = SW_T;  // next round's cell (nobody touches it this round)
         __syncthreads();
         uint32_t count = *fc;
-        const int64_t left = ASC ? (int64_t)n - i_cur : i_cur;  // steps not yet applied
-        const int64_t nvalid = left < SW_T ? left : SW_T;
+        const int64_t left = ASC ? (int64_t)n - i_cur : i_cur;  // steps not yet applied (<= 0: this half is done)
+        const int64_t nvalid = left < 0 ? 0 : (left < SW_T ? left : SW_T);
         if ((int64_t)count > nvalid) count = (uint32_t)nvalid;
-        if (l < count) {
+        if (valid && l < count) {
             A[i] = a_j;
             if (j != (int32_t)i) A[j] = a_i;
         }
 #ifndef SW_NO_PREFETCH
-        if (top_up) { jring[kf & (SW_RING - 1)] = j_next; filled += SW_T; }   // (uniform; slots of steps already applied)
+        if (top_up) { jring[kf & (SW_RING - 1)] = j_next; filled += SW_T; }   // (uniform per half; slots of steps already applied)
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         i_cur += ASC ? (int64_t)count : -(int64_t)count;
         ++round;
+        if (l == 0) act[half] = (exists && (ASC ? i_cur <= (int64_t)n - 1 : i_cur >= 1)) ? 1u : 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
+}
+
+// r04: FULL rounds.  The kernel above ends a round at the first step that shares a slot with an earlier step of the round
+// (the birthday bound: ~0.9 sqrt(i) steps, 470 of 512 at i = 10^6, 2670 rounds per 10^6-step permutation, each a round trip
+// to L2 and four barriers: 10-12 ms per chunk, and the scoring of a chunk waits for exactly that).  But a round's hazards
+// all run through the PARTNER slots of earlier steps, and the hash table that finds them can also resolve them:
+//   descending (the shuffle): step k reads its own slot i_k and its partner slot j_k.  An earlier step a of the round can
+//     have touched either one only as ITS partner (j_a == i_k or j_a == j_k: own slots of earlier steps lie above i_k), and
+//     what it left there is the value v_a its own slot held.  So v_k = v_a of the latest such a for i_k (else memory), the
+//     value that ends up in slot i_k is v_a of the latest such a for j_k (else memory), and slot j_k ends up with v of the
+//     LAST step of the round that has it as partner -- unless it is a processed step's own slot (written by that step).
+//   ascending (the inverse table): a step's own slot is untouched (v_k = i_k); its partner slot may have been touched by
+//     an earlier step as partner (leaving that step's i_a) or as own slot (leaving w_a, what that step took from ITS
+//     partner slot); slot i_k ends up with i_b of the last LATER step that has it as partner, else with w_k.
+// Per key (slot) the table keeps the smallest and the largest step index: enough while no key has three steps below the
+// round's end, so a round ends at the first MIDDLE step of a key (~i^(2/3) steps: every round of 1024 is whole down to
+// i ~ 30 000).  Chains (v_k = v_a = v_a' ...) are rare and resolved by pointer jumping in LDS.  1054 rounds per 10^6-step
+// permutation instead of 2670 (simulation and rule: scripts/swap_rounds_sim.py); sixteen wavefronts per workgroup, the
+// size of the generator's preparation workgroups.
+#define SF_T 1024
+#define SF_HASH 8192      // eight slots per step: a CAS insert seldom probes twice (at two slots per step the slowest wavefront
+                          // of sixteen probed ~10 times, 6000 clocks per round); 96 KB of the CU's 160 KB LDS, cleared entry by entry
+#define SF_HASH_SHIFT 19
+#define SF_RING 4096
+#define SF_NONE 0xffffffffu
+// A barrier that orders LDS only: __syncthreads() carries a global-memory fence, i.e. a wait for every load in flight,
+// and the point of a round is that the hash work runs UNDER the latency of the round's loads (measured, clocks per round
+// with __syncthreads(): loads + first barrier 3800, insert 2600, detect + look-up 6000, values 2000, stores 1800).
+__device__ __forceinline__ void sf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool ASC>
+__global__ __launch_bounds__(SF_T) void k_apply_swaps_full(const int32_t *__restrict__ J, int32_t *__restrict__ perm,
+                                                           int64_t pstride, uint32_t n, int64_t p0, int64_t n_perm)
+{
+    __shared__ uint32_t hkey[SF_HASH], hmin[SF_HASH], hmax[SF_HASH];   // key (slot) | smallest step | 1 + largest step
+    __shared__ uint32_t omin[SF_T], omax[SF_T];   // the same two for the round's OWN slots as somebody's partner, by step (no probing)
+    __shared__ int32_t jring[SF_RING];
+    __shared__ int32_t val[SF_T];       // v_k (descending) / w_k (ascending) once ptr[k] == SF_NONE
+    __shared__ uint32_t ptr[SF_T];      // the step whose value step k takes
+    __shared__ uint32_t first_conf[2], chains[2];
+    const uint32_t l = threadIdx.x;
+    const int64_t p = p0 + blockIdx.x;
+    if (p >= n_perm) return;
+    const uint32_t M = n - 1;           // steps; step s = 0 .. M - 1 handles i = 1 + s (ascending) or n - 1 - s
+    int32_t *A = perm + p * pstride;
+    const int32_t *Jp = J + p * (int64_t)M;
+    // partner of step s: Jp[M - i]
+    auto partner_at = [&](uint32_t s) -> int32_t { return Jp[ASC ? M - 1u - s : s]; };
+    if (!ASC) { for (uint32_t x = l; x < n; x += SF_T) A[x] = (int32_t)x; }
+    else if (l == 0) A[0] = 0;
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t s = r * SF_T + l;
+        jring[s & (SF_RING - 1)] = s < M ? partner_at(s) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < SF_HASH / SF_T; ++k) { hkey[l + SF_T * k] = SF_NONE; hmin[l + SF_T * k] = SF_NONE; hmax[l + SF_T * k] = 0u; }
+    omin[l] = SF_NONE; omax[l] = 0u;
+    uint32_t filled = 2 * SF_T;          // partners of steps [done, filled) are in the ring
+    uint32_t done = 0;                  // steps applied so far
+    if (l < 2) { first_conf[l] = SF_T; chains[l] = 0u; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // the processed steps of a key below k / below the round's end (see above: at most hmin and hmax)
+    auto last_lt = [](uint32_t mn, uint32_t mx1, uint32_t k) -> uint32_t {
+        return (mx1 != 0u && mx1 - 1u < k) ? mx1 - 1u : (mn < k ? mn : SF_NONE);
+    };
+#ifdef SF_PROFILE
+    long long pf[6] = {0, 0, 0, 0, 0, 0};
+#define SF_MARK(x) { const long long t_ = clock64(); pf[x] += t_ - pf_t; pf_t = t_; }
+#else
+#define SF_MARK(x)
+#endif
+    uint32_t round = 0;
+    while (done < M) {
+#ifdef SF_PROFILE
+        long long pf_t = clock64();
+#endif
+        const uint32_t i_cur = ASC ? 1u + done : n - 1u - done;   // the round's first step
+        const uint32_t left = M - done;
+        const uint32_t nvalid = left < SF_T ? left : SF_T;
+        const bool valid = l < nvalid;
+        const uint32_t i = ASC ? i_cur + l : i_cur - l;           // (meaningful if valid)
+        int32_t j = valid ? jring[(done + l) & (SF_RING - 1)] : -1;
+        const bool top_up = filled - done <= 2 * SF_T;
+        const uint32_t sf = filled + l;
+        int32_t j_next = -1;
+        if (top_up && sf < M) j_next = partner_at(sf);
+        if (valid && (uint32_t)j > i) j = (int32_t)i;  // never index outside [0, i], whatever J holds
+        int32_t a_i = (int32_t)i, a_j = 0;
+        if (valid) {  // L1 is bypassed: the values the previous round stored are in L2 (vmcnt wait + barrier)
+            if (!ASC) a_i = __hip_atomic_load(&A[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a_j = __hip_atomic_load(&A[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ascending: may be a slot nobody has written yet; not used then)
+        }
+        // ---- insert: the tables were cleared behind the previous round's last reads ----
+        uint32_t *fc = &first_conf[round & 1];
+        uint32_t h = 0;
+        if (valid) {
+            h = ((uint32_t)j * 2654435761u) >> SF_HASH_SHIFT;
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[h], SF_NONE, (uint32_t)j);
+                if (old == SF_NONE || old == (uint32_t)j) break;
+                h = (h + 1) & (SF_HASH - 1);
+            }
+            atomicMin(&hmin[h], l);
+            atomicMax(&hmax[h], l + 1u);
+            const uint32_t t = ASC ? (uint32_t)j - i_cur : i_cur - (uint32_t)j;   // the step whose own slot is j (if < SF_T)
+            if (t < SF_T) { atomicMin(&omin[t], l); atomicMax(&omax[t], l + 1u); }
+        }
+        sf_lds_barrier();
+        SF_MARK(0)
+        // ---- hazards: middle steps end the round; every step finds where its two values come from ----
+        uint32_t mn = SF_NONE, mx1 = 0u, imn = SF_NONE, imx1 = 0u;   // of the key j / of the key i (my own slot as somebody's partner)
+        uint32_t myptr = SF_NONE, p2 = SF_NONE;
+        if (valid) {
+            mn = hmin[h]; mx1 = hmax[h];
+            imn = omin[l]; imx1 = omax[l];
+            if (mn < l && l + 1u < mx1) atomicMin(fc, l);   // a middle step of its key
+            int32_t v = a_i;
+            if (!ASC) {
+                const uint32_t p1 = last_lt(imn, imx1, l);
+                p2 = j == (int32_t)i ? p1 : last_lt(mn, mx1, l);
+                myptr = p1;
+            } else if (j != (int32_t)i) {
+                const uint32_t a_p = last_lt(mn, mx1, l);
+                const uint32_t t = (uint32_t)j - i_cur;       // the step whose own slot is j (wraps to a large number below i_cur)
+                const bool own = t < l;
+                if (a_p == SF_NONE && !own) v = a_j;
+                else if (a_p != SF_NONE && (!own || a_p >= t)) v = (int32_t)(i_cur + a_p);
+                else myptr = t;
+            }
+            val[l] = v;
+            ptr[l] = myptr;
+            if (myptr != SF_NONE) chains[round & 1] = 1u;
+        }
+        if (l == 0) { first_conf[(round + 1) & 1] = SF_T; chains[(round + 1) & 1] = 0u; }
+        sf_lds_barrier();
+        SF_MARK(1)
+        uint32_t count = *fc;
+        if (count > nvalid) count = nvalid;
+        // chains: a step takes the value of an earlier one, which may itself be waiting (rare; usually no pointer at all;
+        // a pointer of a step beyond the round's end is resolved too, harmlessly)
+        if (chains[round & 1]) {
+            for (;;) {
+                int32_t got = 0;
+                bool ok = false;
+                if (myptr != SF_NONE && ptr[myptr] == SF_NONE) { got = val[myptr]; ok = true; }
+                const int pending = __syncthreads_or(myptr != SF_NONE && !ok);   // (all reads of the iteration are done)
+                if (ok) { val[l] = got; ptr[l] = SF_NONE; myptr = SF_NONE; }
+                __syncthreads();
+                if (!pending) break;
+            }
+        }
+        SF_MARK(2)
+        if (valid && l < count) {
+            const uint32_t my_last = (mx1 != 0u && mx1 - 1u < count) ? mx1 - 1u : (mn < count ? mn : SF_NONE);   // last processed step of key j
+            if (!ASC) {
+                A[i] = p2 == SF_NONE ? a_j : val[p2];
+                if (j != (int32_t)i && (uint32_t)j + count <= i_cur && my_last == l) A[j] = val[l];
+            } else {
+                const uint32_t b = (imx1 != 0u && imx1 - 1u < count) ? imx1 - 1u : (imn < count ? imn : SF_NONE);   // last processed step with partner i
+                if (!(b != SF_NONE && b > l)) A[i] = val[l];
+                if (j != (int32_t)i && my_last == l) A[j] = (int32_t)i;
+            }
+        }
+        sf_lds_barrier();   // every read of the tables and of val is done: clear what this round wrote, under the stores
+        if (valid) {
+            hkey[h] = SF_NONE; hmin[h] = SF_NONE; hmax[h] = 0u;
+            const uint32_t t = ASC ? (uint32_t)j - i_cur : i_cur - (uint32_t)j;
+            if (t < SF_T) { omin[t] = SF_NONE; omax[t] = 0u; }
+        }
+        if (top_up) { jring[sf & (SF_RING - 1)] = j_next; filled += SF_T; }   // (slots of steps already applied)
+        done += count;
+        ++round;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SF_MARK(3)
+    }
+#ifdef SF_PROFILE
+    if (blockIdx.x == 0 && (l == 0 || l == 1000)) printf("swaps_full thread %u: %u rounds; clocks per round: loads issued + insert + barrier %lld, hazards + values + barrier %lld, chains %lld, stores + clear + wait + barrier %lld\n",
+                                  l, round, pf[0] / round, pf[1] / round, pf[2] / round, pf[3] / round);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2245,7 +2576,7 @@ bool permgen_can_swap_inverse(int64_t n) { return n >= SWAPS_WG_MIN_N; }
 
 // inverse = false: rows [p0, p1) of the permutation table (c->perm); true: of its inverse (c->inv), by the same
 // transpositions in ascending order (workgroup kernel only: see permgen_can_swap_inverse)
-int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse)
+int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStream_t s, bool inverse, int pw_req)
 {
     if (job->trivial || p1 <= p0) {
         if (job->trivial && inverse && p1 > p0)
@@ -2255,12 +2586,31 @@ int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStrea
     SC_REQUIRE(!inverse || permgen_can_swap_inverse(job->n), SC_ERR_STATE, "permgen_swap_chunk: inverse tables need n >= %d",
                SWAPS_WG_MIN_N);
     KernelTimerScope ts(c, SC_K_PERM_SWAP, s);
-    if (inverse)
-        hipLaunchKernelGGL(k_apply_swaps_wg<true>, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
-                           c->inv.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
-    else if (job->n >= SWAPS_WG_MIN_N)
-        hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)(p1 - p0)), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
-                           c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    static const int pw_env = getenv("SC_SWAP_PW") ? atoi(getenv("SC_SWAP_PW")) : 0;   // (development: A/B)
+    const int pw = pw_env ? pw_env : pw_req;   // permutations per workgroup
+    const unsigned wgs = (unsigned)(pw == 2 ? (p1 - p0 + 1) / 2 : p1 - p0);
+    // r04 NEGATIVE RESULT, opt-in (SC_SWAP_FULL_ROUNDS=1): whole rounds of 1024 steps (k_apply_swaps_full).  1058 instead of
+    // 2880 rounds per 10^6-step permutation, but a round of sixteen wavefronts on one CU is bound by instruction issue, not by
+    // its trip to L2 (13 k clocks against 6 k): 6.2 instead of 7.2 ms per 128-permutation chunk alone; inside the Moran
+    // pipeline the swaps take 77 instead of 115 ms per step and the generator's chain, which now finds 2048 instead of 1024
+    // long-lived wavefronts and 128 KB of LDS per workgroup in its way, 148 instead of 131 ms: the step 161 against 157.5 ms.
+    const bool full_rounds = getenv("SC_SWAP_FULL_ROUNDS") != nullptr;
+    if (full_rounds && job->n >= SWAPS_WG_MIN_N) {
+        if (inverse) hipLaunchKernelGGL(k_apply_swaps_full<true>, dim3((unsigned)(p1 - p0)), dim3(SF_T), 0, s, c->pg_J.as<int32_t>(),
+                                        c->inv.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+        else hipLaunchKernelGGL(k_apply_swaps_full<false>, dim3((unsigned)(p1 - p0)), dim3(SF_T), 0, s, c->pg_J.as<int32_t>(),
+                                c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    } else if (inverse) {
+        if (pw == 2) hipLaunchKernelGGL((k_apply_swaps_wg<true, 2>), dim3(wgs), dim3(2 * SW_T), 0, s, c->pg_J.as<int32_t>(),
+                                        c->inv.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+        else hipLaunchKernelGGL((k_apply_swaps_wg<true, 1>), dim3(wgs), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+                                c->inv.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    } else if (job->n >= SWAPS_WG_MIN_N) {
+        if (pw == 2) hipLaunchKernelGGL((k_apply_swaps_wg<false, 2>), dim3(wgs), dim3(2 * SW_T), 0, s, c->pg_J.as<int32_t>(),
+                                        c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+        else hipLaunchKernelGGL((k_apply_swaps_wg<false, 1>), dim3(wgs), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+                                c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
+    }
     else
         hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)(p1 - p0)), dim3(64), 0, s, c->pg_J.as<int32_t>(),
                            c->perm.as<int32_t>(), c->p_stride, (uint32_t)job->n, p0, p1);
@@ -2394,7 +2744,7 @@ int sc_perm_counter_rows(sc_ctx *c, uint64_t seed, int64_t n, int64_t p_first, i
     hipLaunchKernelGGL(k_counter_J, dim3(grid), dim3(256), 0, s, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)n,
                        (uint64_t)p_first, n_perm, c->pg_J.as<int32_t>());
     if (n >= SWAPS_WG_MIN_N)
-        hipLaunchKernelGGL(k_apply_swaps_wg<false>, dim3((unsigned)n_perm), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
+        hipLaunchKernelGGL((k_apply_swaps_wg<false, 1>), dim3((unsigned)n_perm), dim3(SW_T), 0, s, c->pg_J.as<int32_t>(),
                            c->perm.as<int32_t>(), c->p_stride, (uint32_t)n, (int64_t)0, n_perm);
     else
         hipLaunchKernelGGL(k_apply_swaps, dim3((unsigned)n_perm), dim3(64), 0, s, c->pg_J.as<int32_t>(),
@@ -2442,7 +2792,7 @@ static int perm_generate_once(sc_ctx *c, uint64_t *state6, int64_t n, int64_t n_
         const int64_t p1 = p0 + PERM_CHUNK < n_perm ? p0 + PERM_CHUNK : n_perm;
         SC_TRY(permgen_scan_chunk(c, &job, p1, c->stream, nullptr, nullptr));
     }
-    SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream, false));
+    SC_TRY(permgen_swap_chunk(c, &job, 0, n_perm, c->stream, false, 1));
     c->perm_forward_valid = true;
     SC_HIP(hipStreamSynchronize(c->stream));
     for (hipStream_t sp : c->stream_pg)

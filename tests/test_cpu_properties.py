@@ -166,3 +166,15 @@ def test_lattice_count_is_the_exact_arithmetic_count(seed, n, k):
         T = sum(x[i] * S[perms[p][i]] for i in range(n))
         diffs.add(exact - (T - mean * sum(S)))
     assert len(diffs) > 1                                                     # not a constant offset: counts would differ
+
+
+def test_swap_rounds_rule_equals_the_sequential_shuffle():
+    """The rule of k_apply_swaps_full (whole rounds of T steps, hazards resolved through the smallest / largest step per
+    partner slot, cut at the first middle step) on the CPU: both directions, small n and T, i.e. conflicts in every round."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(__file__), "..", "scripts", "swap_rounds_sim.py")
+    spec = importlib.util.spec_from_file_location("swap_rounds_sim", path)
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    assert sim.check(seed=11, trials=200) is None

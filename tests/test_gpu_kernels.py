@@ -378,6 +378,31 @@ def test_moran_seeded_bench_schedule_block_parallel_generator(ctx, oracle):
     assert_counts_match(one["count_ge"][cols], tab)
 
 
+def test_whole_round_swap_kernel_returns_the_same_tables(ctx, oracle, monkeypatch):
+    """SC_SWAP_FULL_ROUNDS=1 (opt-in, a negative result of r04: DESIGN.md 4.3) applies the Fisher-Yates transpositions in
+    whole rounds of 1024 steps, hazards resolved through an LDS table instead of ending the round.  Forward tables equal
+    numpy's; the inverse-only pipeline scores bit-equal to the default kernel (its rounds are cut at every shared slot)."""
+    from spatialcore_amd._lib import rng_state_words, perm_numpy_host
+
+    for seed, n, P in ((5, 65537, 9), (21, 300007, 6), (9, 1048577, 3)):
+        want = perm_numpy_host(rng_state_words(np.random.default_rng(seed)), n, P)
+        monkeypatch.setenv("SC_SWAP_FULL_ROUNDS", "1")
+        got = ctx.generate_permutations(rng_state_words(np.random.default_rng(seed)), n, P, fetch=True)
+        monkeypatch.delenv("SC_SWAP_FULL_ROUNDS")
+        np.testing.assert_array_equal(got, want)
+    n, G, P = 70001, 6, 150
+    coords, X = synth(n, G, 2, dtype=np.float32, sparse_x=False)
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, np.arange(G))
+    ref = ctx.moran_seeded(rng_state_words(np.random.default_rng(11)), P)
+    monkeypatch.setenv("SC_SWAP_FULL_ROUNDS", "1")
+    got = ctx.moran_seeded(rng_state_words(np.random.default_rng(11)), P)
+    monkeypatch.delenv("SC_SWAP_FULL_ROUNDS")
+    for key in ("I", "sims", "count_ge"):
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+
+
 def test_moran_seeded_inverse_only_tables(ctx, oracle):
     """n >= 65536 with a float32 matrix: the pipeline never builds the permutation table, only its inverse (the same
     Fisher-Yates transpositions applied in ascending order).  Scores must equal the two-step path bit for bit, and
