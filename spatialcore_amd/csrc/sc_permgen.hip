@@ -178,6 +178,7 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     // fast path: neither a mask change, nor the end of a permutation, nor the end of the job can
     // happen within SCAN_D accepts
     const bool fast = i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit;
+#ifdef SCAN_R03_PATHS
     if (fast) {
         uint32_t thr = i0, gap = 0xffffffffu;
         bits_t bits = 0;
@@ -215,6 +216,83 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     const uint32_t cnt = off - c_in;
     r.end = end;
     r.cnt = cnt; r.bits = bits; r.gap = 0; r.fast = 0;
+#else
+    // r04: ONE pass per wavefront (r03 ran the fast loop for its fast lanes and then the general loop for the others: the
+    // wavefront that holds a band change -- the one every round of a computed block waits for -- paid both, ~310
+    // instructions).  All lanes fast: the fast loop.  Otherwise every lane takes the general loop, which also tracks the
+    // gap, so a fast lane leaves it with exactly what the fast loop would have given it; and the job's end is looked for
+    // only by wavefronts that can reach it.
+    if (!__any(!fast)) {
+        uint32_t thr = i0, gap = 0xffffffffu;
+        bits_t bits = 0;
+#pragma unroll
+        for (int s = 0; s < SCAN_D; ++s) {
+            const uint32_t v = u[s] & mask;
+            const int32_t d = (int32_t)(thr - v);        // both < 2^31; accepted iff d >= 0
+            const uint32_t acc = (uint32_t)(~d) >> 31;
+            gap = min(gap, (uint32_t)(d ^ (d >> 31)));   // d if accepted, -d - 1 if rejected
+            bits |= (bits_t)acc << s;
+            thr -= acc;
+        }
+        r.cnt = i0 - thr; r.bits = bits; r.gap = gap; r.fast = 1;
+        return;
+    }
+    // general path, branch-free: the band / permutation bookkeeping is evaluated for every draw (it is the identity
+    // unless the draw was accepted) instead of a divergent branch tree
+    uint32_t i = i0, gap = 0xffffffffu;
+    bits_t bits = 0;
+    if (!__any(!(c_in + SCAN_D < limit))) {   // (wavefront-uniform) the job does not end inside these draws
+#ifndef SCAN_WRAP_ALWAYS
+#define SCAN_WRAP_ALWAYS 0   // (A/B builds)
+#endif
+        if (!SCAN_WRAP_ALWAYS && !__any(i0 <= SCAN_D)) {           // (wavefront-uniform) nor does a permutation: mask changes only
+#pragma unroll
+            for (int s = 0; s < SCAN_D; ++s) {
+                const uint32_t v = u[s] & mask;
+                const int32_t d = (int32_t)(i - v);          // accepted iff d >= 0
+                const uint32_t acc = (uint32_t)(~d) >> 31;
+                gap = min(gap, (uint32_t)(d ^ (d >> 31)));
+                bits |= (bits_t)acc << s;
+                i -= acc;
+                const uint32_t half = mask >> 1;
+                mask = i <= half ? half : mask;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SCAN_D; ++s) {
+                const uint32_t v = u[s] & mask;
+                const int32_t d = (int32_t)(i - v);
+                const uint32_t acc = (uint32_t)(~d) >> 31;
+                gap = min(gap, (uint32_t)(d ^ (d >> 31)));
+                bits |= (bits_t)acc << s;
+                i -= acc;
+                const bool wrap = i == 0;                 // the permutation is complete: the next one starts at M
+                const uint32_t half = mask >> 1;
+                mask = wrap ? top_mask : (i <= half ? half : mask);
+                i = wrap ? M : i;
+            }
+        }
+        r.cnt = (uint32_t)__popcll((unsigned long long)bits);
+        r.bits = bits; r.gap = fast ? gap : 0u; r.fast = fast ? 1u : 0u;
+        return;
+    }
+    uint32_t off = c_in, end = 0;
+#pragma unroll
+    for (int s = 0; s < SCAN_D; ++s) {
+        const uint32_t v = u[s] & mask;
+        const uint32_t acc = ((off < limit) & (v <= i)) ? 1u : 0u;
+        bits |= (bits_t)acc << s;
+        off += acc;
+        i -= acc;
+        end = (acc & (off == limit ? 1u : 0u)) ? (uint32_t)s + 1 : end;
+        const bool wrap = i == 0;
+        const uint32_t half = mask >> 1;
+        mask = wrap ? top_mask : (i <= half ? half : mask);
+        i = wrap ? M : i;
+    }
+    r.end = end;
+    r.cnt = off - c_in; r.bits = bits; r.gap = 0; r.fast = 0;
+#endif
 }
 
 // Is the cached result still the exact result for entering count c_new?  On the fast path every
