@@ -279,6 +279,14 @@ int sc_local_moran_classify(sc_ctx *ctx, const float *p_tab, const float *padj_t
  * #{p : |float32(z_x[i] * (W z_y[perm_p])[i])| >= |L_local[i]|} over rows [perm_row0, +n_perm). */
 int sc_lee_local(sc_ctx *ctx, int32_t gene_x, int32_t gene_y, int64_t n_perm, int64_t perm_row0,
                  double *zx_out, double *lag_out, double *L_local_out, int32_t *count_out);
+/* The whole pair body of lees_l_local (AC:1373-1413) as one pipeline behind the numpy-exact generator: equal, bit for bit
+ * and in the generator state it leaves, to sc_perm_generate(state6, n_cells, n_perm_global + n_perm_local), sc_lee for the
+ * pair on rows [0, n_perm_global) (AC:1394-1400: global L and the count of |L_perm| >= |L|) and sc_lee_local on rows
+ * [n_perm_global, +n_perm_local) (AC:1402-1413) -- with the sums and counts taken chunk by chunk while the generator runs.
+ * Both genes need a positive variance (the reference skips such pairs before it gets here, AC:1380-1392). */
+int sc_lee_local_seeded(sc_ctx *ctx, uint64_t *state6, int32_t gene_x, int32_t gene_y, int64_t n_perm_global,
+                        int64_t n_perm_local, double *L_out, int64_t *count_abs_ge_out, double *zx_out, double *lag_out,
+                        double *L_local_out, int32_t *count_out);
 
 /* ---- N3: domain distances (reference src/spatialcore/spatial/distance.py) -----------------------
  * sc_nearest_2d replaces cKDTree(target_coords).query(source_coords, k=1) (distance.py:222-232,

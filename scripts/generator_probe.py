@@ -39,5 +39,8 @@ if os.environ.get("SC_PHI_PROFILE"):   # library built with EXTRA=-DPHI_PROFILE
     nb = max(int(prof[25]), 1)
     print(f"fixed point of the computed blocks: first evaluation (guess + 16 draws) {int(prof[24]) / nb:.0f} clocks of thread 0; wavefronts that recompute "
           f"after round 1 / 2 / 3 / later: {int(prof[26]) / nb:.1f} / {int(prof[27]) / nb:.1f} / {int(prof[28]) / nb:.1f} / {int(prof[29]) / nb:.1f} of 16 per block")
+    nr = max(int(prof[11]), 1)
+    print(f"rounds of the computed blocks: {nr / jobs:.1f} per permutation; wavefront 0 (which seldom recomputes) works {int(prof[3]) / nr:.0f} clocks a round "
+          f"and waits {int(prof[7]) / nr:.0f} at the round's barrier for the wavefronts that do")
 else:
     print(f"last job: {int(st[4])} blocks by lookup in {int(st[6])} segment lookups, {int(st[7]) & 0xffffffff} segments block by block (window missed), {int(st[7]) >> 32} blocks by fresh table; {int(st[5])} computed")

@@ -75,6 +75,7 @@ SYMBOLS = {
     "sc_local_moran_hist": [_P, _P],
     "sc_local_moran_classify": [_P, _P, _P, _P, c_float, _P, _P, _P],
     "sc_lee_local": [_P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P],
+    "sc_lee_local_seeded": [_P, _P, c_int32, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "sc_nearest_2d": [_P, _P, c_int64, _P, c_int64, _P, _P],
     "sc_pairwise_2d": [_P, _P, c_int64, _P, c_int64, POINTER(c_double), POINTER(c_double)],
     "sc_nearest_excluding_2d": [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
@@ -564,6 +565,22 @@ class Context:
         _check(self._lib.sc_lee_local(self._h, int(gene_x), int(gene_y), int(n_perm), int(perm_row0), _ptr(zx),
                                       _ptr(lag), _ptr(L), _ptr(cnt)))
         return {"zx": zx, "lag": lag, "L_local": L, "count": cnt}
+
+    def lee_local_seeded(self, words: np.ndarray, n_cells: int, gene_x: int, gene_y: int, n_perm_global: int, n_perm_local: int):
+        """generate_permutations + lee (rows [0, n_perm_global)) + lee_local (the rows behind) for one pair, as one
+        pipeline behind the generator; `words` (numpy generator state) is advanced in place."""
+        zx = np.empty(n_cells, dtype=np.float64)
+        lag = np.empty(n_cells, dtype=np.float64)
+        L_local = np.empty(n_cells, dtype=np.float64)
+        cnt = np.zeros(n_cells, dtype=np.int32) if n_perm_local > 0 else None
+        L = np.zeros(1, dtype=np.float64)
+        ge = np.zeros(1, dtype=np.int64)
+        w = _c(words, np.uint64)
+        _check(self._lib.sc_lee_local_seeded(self._h, _ptr(w), int(gene_x), int(gene_y), int(n_perm_global), int(n_perm_local),
+                                             _ptr(L), _ptr(ge), _ptr(zx), _ptr(lag), _ptr(L_local), _ptr(cnt)))
+        if w is not words:
+            words[...] = w
+        return {"L": float(L[0]), "count_abs_ge": int(ge[0]), "zx": zx, "lag": lag, "L_local": L_local, "count": cnt}
 
     # ---- N3 ---------------------------------------------------------------------------------
     def nearest(self, targets, queries):

@@ -3476,3 +3476,120 @@ extern "C" int sc_lee_local(sc_ctx *c, int32_t gene_x, int32_t gene_y, int64_t n
     SC_HIP(hipStreamSynchronize(c->stream));
     return SC_OK;
 }
+
+// r04: the pair body of lees_l_local as ONE pipeline (r03's verdict: a generator call and two device calls per pair, each
+// waiting for the one before).  Equal to
+//     sc_perm_generate(state6, n, n_perm_global + n_perm_local);  sc_lee(x, y, offset 0, n_perm_global);
+//     sc_lee_local(x, y, n_perm_local, perm_row0 = n_perm_global)
+// -- the same kernels on the same rows, results bit for bit, the generator state advanced by the same draws -- with the
+// permuted sums of the global statistic and the per-cell counts taken chunk by chunk behind the generator (which is 85 % of
+// the three calls' time at 10^6 cells), like sc_local_moran_seeded.
+extern "C" int sc_lee_local_seeded(sc_ctx *c, uint64_t *state6, int32_t gene_x, int32_t gene_y, int64_t n_perm_global,
+                                   int64_t n_perm_local, double *L_out, int64_t *count_abs_ge_out, double *zx_out,
+                                   double *lag_out, double *L_local_out, int32_t *count_out)
+{
+    SC_REQUIRE(c && state6 && L_out && zx_out && lag_out && L_local_out, SC_ERR_INVALID, "sc_lee_local_seeded: null pointer");
+    SC_REQUIRE(n_perm_global >= 0 && n_perm_local >= 0 && n_perm_global + n_perm_local >= 1 &&
+               n_perm_global + n_perm_local <= (1 << 24), SC_ERR_INVALID, "sc_lee_local_seeded: permutation counts out of range");
+    SC_REQUIRE(n_perm_local == 0 || count_out, SC_ERR_INVALID, "sc_lee_local_seeded: count_out required when n_perm_local > 0");
+    SC_REQUIRE(n_perm_global == 0 || count_abs_ge_out, SC_ERR_INVALID, "sc_lee_local_seeded: count_abs_ge_out required when n_perm_global > 0");
+    SC_HIP(hipSetDevice(c->device));
+    SC_REQUIRE(c->e_n > 0, SC_ERR_STATE, "sc_lee_local_seeded: no expression loaded");
+    SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_lee_local_seeded: graph missing or size mismatch");
+    SC_REQUIRE(gene_x >= 0 && gene_x < c->e_genes && gene_y >= 0 && gene_y < c->e_genes, SC_ERR_INVALID,
+               "sc_lee_local_seeded: gene index outside the loaded set");
+    const int64_t n = c->e_n, T = c->e_tiles, Pg = n_perm_global, Pl = n_perm_local;
+    const int blocks = (int)ceil_div64(n, LEE_CELLS_PER_BLOCK);
+    const unsigned gcol = (unsigned)ceil_div64(n, 256);
+    double *va = nullptr, *vlag_g = nullptr, *vu = nullptr, *vb = nullptr, *vlag = nullptr, *vL = nullptr;
+    int32_t *vcnt = nullptr;
+    auto prepare = [&]() -> int {
+        // ---- sc_lee's operands: z-scores (population sd), Lag = W Z, u = W^T z_x ----
+        SC_TRY(expr_center(c));
+        hipLaunchKernelGGL(k_div_sd, dim3((unsigned)ceil_div64(n * SC_TILE, 256), (unsigned)T), dim3(256), 0, c->stream,
+                           c->Z.as<double>(), c->g_var.as<double>(), n);
+        SC_TRY(c->Lag.ensure((size_t)T * (size_t)n * SC_TILE * sizeof(double), &c->mem));
+        SC_TRY(launch_lag(c, c->g_indptr, c->g_indices, c->g_data, c->Z.as<double>(), c->Lag.as<double>()));
+        double var[2];
+        SC_HIP(hipMemcpyAsync(&var[0], c->g_var.as<double>() + gene_x, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipMemcpyAsync(&var[1], c->g_var.as<double>() + gene_y, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SC_HIP(hipStreamSynchronize(c->stream));
+        SC_REQUIRE(var[0] > 0.0 && var[1] > 0.0, SC_ERR_INVALID, "sc_lee_local_seeded: a gene of the pair has zero variance");
+        SC_TRY(c->lee_a.ensure(sizeof(double) * (size_t)n * 8, &c->mem));
+        va = c->lee_a.as<double>(); vlag_g = va + n; vu = va + 2 * n; vb = va + 3 * n;   // va = z_x, vb = z_y: sc_lee_local's vx, vy too
+        vlag = va + 4 * n; vL = va + 5 * n;
+        vcnt = reinterpret_cast<int32_t *>(va + 6 * n);
+        SC_TRY(c->lee_b.ensure(sizeof(double) * (size_t)blocks * (size_t)(Pg + 1), &c->mem));
+        SC_TRY(c->lee_out.ensure(sizeof(double) * (size_t)(Pg + 1 > T * SC_TILE ? Pg + 1 : T * SC_TILE), &c->mem));
+        if (Pg > 0) SC_TRY(sc_graph_ensure_transpose(c));
+        hipLaunchKernelGGL(k_extract_col, dim3(gcol), dim3(256), 0, c->stream, c->Z.as<double>(), n, (int64_t)gene_x, va);
+        hipLaunchKernelGGL(k_extract_col, dim3(gcol), dim3(256), 0, c->stream, c->Lag.as<double>(), n, (int64_t)gene_y, vlag_g);
+        hipLaunchKernelGGL(k_vec_dot, dim3(blocks), dim3(256), 0, c->stream, va, vlag_g, n, c->lee_b.as<double>() + (size_t)Pg * blocks);
+        hipLaunchKernelGGL(k_extract_col, dim3(gcol), dim3(256), 0, c->stream, c->Z.as<double>(), n, (int64_t)gene_y, vb);
+        if (Pg > 0)
+            sc_launch_spmv_vec(c, c->gt_indptr.as<int64_t>(), c->gt_indices.as<int32_t>(), c->gt_data.as<double>(), va, vu, n);
+        // ---- sc_lee_local's: lag = W z_y on the vector, L_local = z_x * lag ----
+        sc_launch_spmv_vec(c, c->g_indptr.as<int64_t>(), c->g_indices.as<int32_t>(), c->g_data.as<double>(), vb, vlag, n);
+        hipLaunchKernelGGL(k_vec_mul, dim3(gcol), dim3(256), 0, c->stream, va, vlag, vL, n);
+        if (Pl > 0 && !c->lm_direct) {
+            SC_TRY(sc_graph_ensure_order(c));
+            SC_TRY(c->lm_ys.ensure(sizeof(double) * (size_t)LL_PERM_BATCH * (size_t)n, &c->mem));
+        }
+        SC_HIP(hipGetLastError());
+        return SC_OK;
+    };
+    auto score = [&](int64_t p0, int64_t p1) -> int {
+        KernelTimerScope ts(c, SC_K_LEE_PERM);
+        const int64_t a1 = p1 < Pg ? p1 : Pg;
+        if (p0 < a1)   // rows of the global statistic
+            hipLaunchKernelGGL(k_vec_gather_dot, dim3(blocks, (unsigned)(a1 - p0)), dim3(256), 0, c->stream, vu, vb,
+                               c->perm.as<int32_t>() + p0 * c->p_stride, c->p_stride, n, c->lee_b.as<double>() + (size_t)p0 * blocks);
+        const int64_t b0 = p0 > Pg ? p0 : Pg;
+        if (b0 < p1 && c->lm_direct) {   // r01 form (development A/B): all rows at the end
+            if (p1 == Pg + Pl)
+                hipLaunchKernelGGL(k_lee_local_count, dim3(gcol), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                                   c->g_indices.as<int32_t>(), c->g_data.as<double>(), va, vb, vL,
+                                   c->perm.as<int32_t>() + Pg * c->p_stride, c->p_stride, (int)Pl, vcnt, n);
+        } else {
+            for (int64_t q0 = b0; q0 < p1; q0 += LL_PERM_BATCH) {   // rows of the per-cell counts
+                const int nb = (int)(p1 - q0 < LL_PERM_BATCH ? p1 - q0 : LL_PERM_BATCH);
+                hipLaunchKernelGGL(k_lee_local_gather, dim3(gcol, (unsigned)nb), dim3(256), 0, c->stream, vb,
+                                   c->g_order.as<int32_t>(), c->perm.as<int32_t>() + q0 * c->p_stride, c->p_stride, n, c->lm_ys.as<double>());
+                hipLaunchKernelGGL(k_lee_local_count_sorted, dim3(gcol), dim3(256), 0, c->stream, c->g_indptr.as<long long>(),
+                                   c->g_indices_r.as<int32_t>(), c->g_data.as<double>(), c->g_order.as<int32_t>(), va,
+                                   c->lm_ys.as<double>(), vL, nb, vcnt, n, q0 == Pg ? 1 : 0);
+            }
+        }
+        SC_HIP(hipGetLastError());
+        return SC_OK;
+    };
+    const int ahead = c->pg_ahead;
+    c->pg_ahead = 2;
+    int rc = sc_perm_pipeline(c, state6, n, Pg + Pl, 0, prepare, score);
+    if (rc == SC_PERMGEN_RETRY) {   // the block-parallel scan failed its verification: everything restarts at permutation 0
+        const int mode = c->pg_mode;
+        c->pg_mode = 1;
+        rc = sc_perm_pipeline(c, state6, n, Pg + Pl, 0, prepare, score);
+        c->pg_mode = mode;
+    }
+    c->pg_ahead = ahead;
+    SC_TRY(rc);
+    std::vector<double> host((size_t)Pg + 1);
+    hipLaunchKernelGGL(k_row_sum, dim3((unsigned)ceil_div64(Pg + 1, 256)), dim3(256), 0, c->stream, c->lee_b.as<double>(),
+                       (int)(Pg + 1), blocks, c->lee_out.as<double>());
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(host.data(), c->lee_out.p, sizeof(double) * (size_t)(Pg + 1), hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(zx_out, va, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(lag_out, vlag, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipMemcpyAsync(L_local_out, vL, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (Pl > 0) SC_HIP(hipMemcpyAsync(count_out, vcnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SC_HIP(hipStreamSynchronize(c->stream));
+    const double L = host[(size_t)Pg];
+    *L_out = L;
+    if (count_abs_ge_out) {
+        int64_t cnt = 0;
+        for (int64_t p = 0; p < Pg; ++p) cnt += fabs(host[(size_t)p]) >= fabs(L) ? 1 : 0;
+        *count_abs_ge_out = cnt;
+    }
+    return SC_OK;
+}

@@ -482,6 +482,9 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
 #endif
     excl = 0; total_cnt = 0;
     uint32_t recomputed = 1u;
+#ifdef PHI_PROFILE
+    long long pf_r = 0;
+#endif
     // TAIL: only where the permutation that ends is not the job's last (its end is the job's `limit`, which the lanes do not know)
     if (TAIL) {
         if (tau == 0) ts->open = (left > (uint64_t)rem_block && rem_block <= SCAN_BLOCK) ? 1u : 0u;
@@ -490,7 +493,15 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
     for (int iter = 0;; ++iter) {
         const uint32_t incl = wave_inclusive_scan(r.cnt);
         if (lane == 63) sh.wsum[parity][wave] = incl | (recomputed << 31);
+#ifdef PHI_PROFILE
+        const long long pf_b0 = clock64();
+        if (rounds_out && tau == 0 && iter > 0) atomicAdd(&g_phi_prof[3], (unsigned long long)(pf_b0 - pf_r));   // wavefront 0's own work of a round
+#endif
         __syncthreads();
+#ifdef PHI_PROFILE
+        pf_r = clock64();
+        if (rounds_out && tau == 0) { atomicAdd(&g_phi_prof[7], (unsigned long long)(pf_r - pf_b0)); atomicAdd(&g_phi_prof[11], 1ull); }   // its wait at the barrier
+#endif
         const uint32_t mine = lane < NW ? sh.wsum[parity][lane] : 0u;
         const bool tail_open = TAIL && ts->open != 0u;
         const uint32_t fst = (tail_open && lane < NW) ? ts->fst[parity][lane] : 0xffffffffu;

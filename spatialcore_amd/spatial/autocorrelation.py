@@ -820,23 +820,25 @@ def lees_l_local(
         cell_p = compute_cell_pvalues and n_permutations > 0
         global_pvalue = 1.0
         if n_permutations > 0:
-            # global block first, then the per-cell block, from the same stream (AC:1394-1408)
-            ctx.generate_permutations(words, n_cells, n_permutations * (2 if cell_p else 1))
-            g = ctx.lee([sx], [sy], [0], n_permutations)
-            global_pvalue = float((g["count_abs_ge"][0] + 1) / (n_permutations + 1))
+            # global block first, then the per-cell block, from the same stream (AC:1394-1408): one pipeline on the device,
+            # the permuted sums and the per-cell counts taken chunk by chunk behind the generator
+            loc = ctx.lee_local_seeded(words, n_cells, sx, sy, n_permutations, n_permutations if cell_p else 0)
+            global_pvalue = float((loc["count_abs_ge"] + 1) / (n_permutations + 1))
+            L_global = loc["L"]
         else:
             g = ctx.lee([sx], [sy], None, 0)
             if compute_cell_pvalues:
                 logger.warning("compute_cell_pvalues=True but n_permutations=0; p-values will be 1.0")
-        L_global = float(g["L"][0])
-        loc = ctx.lee_local(n_cells, sx, sy, n_permutations if cell_p else 0, n_permutations if cell_p else 0)
+            L_global = float(g["L"][0])
+            loc = ctx.lee_local(n_cells, sx, sy, 0, 0)
         p_values = np.ones(n_cells, dtype=np.float32)
         if cell_p:
             p_values = ((loc["count"] + 1) / (n_permutations + 1)).astype(np.float32)
         quadrants = _classify_quadrants(loc["zx"], loc["lag"], p_values if significance_filter else None, alpha)
-        labels = np.array(categories)[quadrants]
         adata.obs[f"{key}_lees_l"] = loc["L_local"].astype(np.float32)
-        adata.obs[f"{key}_quadrant"] = pd.Categorical(labels, categories=categories)
+        # (the same Categorical as pd.Categorical(labels, categories=...) of AC:1429, built from the codes: 0.7 instead of
+        # 260 ms per pair at 10^6 cells)
+        adata.obs[f"{key}_quadrant"] = pd.Categorical.from_codes(quadrants, categories=categories)
         adata.obs[f"{key}_pvalue"] = p_values.astype(np.float32)
         cnt = np.bincount(quadrants, minlength=5)
         adata.uns[f"{key}_lees_l_params"] = {

@@ -378,6 +378,38 @@ def test_moran_seeded_bench_schedule_block_parallel_generator(ctx, oracle):
     assert_counts_match(one["count_ge"][cols], tab)
 
 
+@pytest.mark.parametrize("n,P,cell_p", [(3000, 40, True), (70001, 150, True), (140001, 300, True), (140001, 99, False)])
+def test_lee_local_seeded_equals_the_three_calls(ctx, oracle, n, P, cell_p):
+    """sc_lee_local_seeded (the pair body of lees_l_local as one pipeline behind the generator) == sc_perm_generate +
+    sc_lee + sc_lee_local on the same rows: every output bit for bit, and the generator state it leaves."""
+    from spatialcore_amd._lib import rng_state_words
+
+    coords, X = synth(n, 5, 3, sparse_x=False)
+    ctx.knn(coords, 6, fetch=False)
+    ctx.graph_from_knn(1.0 / 6)
+    ctx.set_expression(X, np.arange(5))
+    Pl = P if cell_p else 0
+    w1 = rng_state_words(np.random.default_rng(5))
+    for sx, sy in ((0, 1), (3, 2)):          # two pairs continue the one stream
+        w0 = w1.copy()
+        ctx.generate_permutations(w0, n, P + Pl)
+        g = ctx.lee([sx], [sy], [0], P)
+        loc = ctx.lee_local(n, sx, sy, Pl, P if cell_p else 0)
+        got = ctx.lee_local_seeded(w1, n, sx, sy, P, Pl)
+        np.testing.assert_array_equal(w1, w0)
+        assert got["L"] == float(g["L"][0]) and got["count_abs_ge"] == int(g["count_abs_ge"][0])
+        for key in ("zx", "lag", "L_local"):
+            np.testing.assert_array_equal(got[key], loc[key], err_msg=key)
+        if cell_p:
+            np.testing.assert_array_equal(got["count"], loc["count"])
+        else:
+            assert got["count"] is None
+    Xz = X.copy(); Xz[:, 4] = 2.0
+    ctx.set_expression(Xz, np.arange(5))
+    with pytest.raises(ValueError):
+        ctx.lee_local_seeded(rng_state_words(np.random.default_rng(5)), n, 0, 4, P, Pl)
+
+
 def test_whole_round_swap_kernel_returns_the_same_tables(ctx, oracle, monkeypatch):
     """SC_SWAP_FULL_ROUNDS=1 (opt-in, a negative result of r04: DESIGN.md 4.3) applies the Fisher-Yates transpositions in
     whole rounds of 1024 steps, hazards resolved through an LDS table instead of ending the round.  Forward tables equal
