@@ -12,5 +12,5 @@ for f in sc_api sc_moran sc_graph sc_perm sc_permgen sc_comm sc_lee; do
 done
 wait
 for f in sc_api sc_moran sc_graph sc_perm sc_permgen sc_comm sc_lee; do test -f $out/$f.o || { echo "build_variant: $f.hip did not compile"; exit 1; }; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/spatialcore_amd/libvar_$name.so $out/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/spatialcore_amd/libvar_$name.so $out/*.o -ldl -pthread
 echo built spatialcore_amd/libvar_$name.so

@@ -96,6 +96,7 @@ int sc_timer_collect(sc_ctx *c)
         if (sp) SC_HIP(hipStreamSynchronize(sp));
     if (c->stream_px) SC_HIP(hipStreamSynchronize(c->stream_px));
     if (c->stream_fr) SC_HIP(hipStreamSynchronize(c->stream_fr));
+    if (c->stream_out) SC_HIP(hipStreamSynchronize(c->stream_out));
     for (int k = 0; k < SC_K_COUNT_; ++k) {
         KTimer &t = c->timers[k];
         for (auto &ev : t.pending) {
@@ -178,7 +179,7 @@ int sc_ctx_destroy(sc_ctx *c)
                     &c->g_z2, &c->g_scale, &c->g_Inum, &c->g_I, &c->red_tmp, &c->perm, &c->perm_flag,
                     &c->partial, &c->sims, &c->counts, &c->sim_sum, &c->sim_sumsq, &c->lee_a,
                     &c->lee_b, &c->lee_out, &c->lee_pairs, &c->lee_U, &c->lee_Zc, &c->lee_Uc, &c->lee_part, &c->lee_obs, &c->lee_cnt,
-                    &c->lee_rowmap, &c->lee_lperm, &c->g_slag, &c->g_xsum, &c->g_flags, &c->g_xmax, &c->g_lat, &c->g_meanc, &c->g_seff, &c->g_corr, &c->g_thr, &c->sims_raw, &c->g_order, &c->g_rank, &c->g_indices_r, &c->g_w32, &c->g_erow_r, &c->lm_ys, &c->lm_tab, &c->s0_tmp, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_flags, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
+                    &c->lee_rowmap, &c->lee_lperm, &c->g_slag, &c->g_xsum, &c->g_flags, &c->g_xmax, &c->g_lat, &c->g_meanc, &c->g_seff, &c->g_corr, &c->g_thr, &c->sims_raw, &c->g_order, &c->g_rank, &c->g_indices_r, &c->g_w32, &c->g_erow_r, &c->lm_ys, &c->lm_out, &c->lm_tab, &c->s0_tmp, &c->pg_J, &c->pg_raw, &c->pg_out, &c->pg_flags, &c->pg_bits, &c->pg_enter, &c->pg_sblk,
                     &c->pg_desc, &c->pg_tbits, &c->pg_events, &c->pg_hard, &c->pg_seg, &c->pg_ctbits, &c->pg_segmode, &c->pg_seglist, &c->pg_fresh, &c->nib_map,
                     &c->np_cnt, &c->np_comp, &c->np_leaves, &c->np_leafsum};
     for (DBuf *b : bufs) b->release(&c->mem);
@@ -199,6 +200,7 @@ int sc_ctx_destroy(sc_ctx *c)
         if (sp) (void)hipStreamDestroy(sp);
     if (c->stream_px) (void)hipStreamDestroy(c->stream_px);
     if (c->stream_fr) (void)hipStreamDestroy(c->stream_fr);
+    if (c->stream_out) (void)hipStreamDestroy(c->stream_out);
     for (hipEvent_t e : c->pg_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);

@@ -70,6 +70,7 @@ struct sc_ctx {
     hipStream_t stream_pg[4] = {};    // block-parallel scan: the chip prepares blocks here ahead of the chain
     hipStream_t stream_px = nullptr;     // ... and verifies + expands a finished chunk here, beside the next chunk's chain
     hipStream_t stream_fr = nullptr;     // ... and the fresh-table helpers of a chain launch live here (k_fresh)
+    hipStream_t stream_out = nullptr;    // r04: result copies that run beside a pipeline, issued by a helper thread (sc_local_moran_seeded)
     hipEvent_t pg_ev[34] = {};        // rings of events between the preparation and the chain launches + start marker
     int pg_mode = 0;                  // 0 auto, 1 sequential scan only, 2 fault injection (tests)
     bool pg_streams_serial = false;   // a wait on a hand-over word gave up once: the streams of this process do not run
@@ -173,6 +174,7 @@ struct sc_ctx {
     bool lm_direct = false;  // local Moran per-cell counts: the r01 one-kernel form instead of the two-phase sorted form (A/B)
     bool lm_valid = false;   // z / lag / counts of the last sc_local_moran are still resident
     int64_t lm_perms = 0;
+    DBuf lm_out;             // local Moran: row-major staging of one output array for the helper thread's device-to-host copies
     DBuf lm_ys;              // local Moran: the permuted z rows (or uint8 code rows) of a batch of permutations, in the graph's processing order
     DBuf lm_tab;             // local Moran, code rows: z and w z per (gene, value)
     // first half of the Moran preparation, enqueued ahead of the generator by sc_moran_seeded_begin (sc_moran.hip)

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <functional>
+#include <thread>
 #include <vector>
 
 #include "sc_ctx.h"
@@ -3143,13 +3144,14 @@ static int lm_count(sc_ctx *c, const LmJob &j, int64_t row0, int64_t p0, int64_t
 
 // un-tile into row-major (cells x genes) staging and copy back
 static int lm_finish(sc_ctx *c, const LmJob &j, int64_t n_perm, float *z_out, float *lag_out, float *I_out,
-                     int32_t *count_out, uint8_t *zero_var_out)
+                     int32_t *count_out, uint8_t *zero_var_out, bool arrays_done = false)
 {
     const int64_t n = j.n, G = j.G;
     SC_TRY(c->lee_a.ensure(sizeof(float) * (size_t)n * (size_t)G, &c->mem));
     unsigned gu = (unsigned)ceil_div64(n * G, 256);
     struct { const float *src; float *dst; } outs[3] = {{j.Z32, z_out}, {j.Lag32, lag_out}, {j.I32, I_out}};
     for (auto &o : outs) {
+        if (arrays_done) break;   // (a helper thread has copied them out beside the pipeline)
         hipLaunchKernelGGL(k_untile<float>, dim3(gu), dim3(256), 0, c->stream, o.src, c->lee_a.as<float>(), n, G);
         SC_HIP(hipMemcpyAsync(o.dst, c->lee_a.p, sizeof(float) * (size_t)n * (size_t)G, hipMemcpyDeviceToHost,
                               c->stream));
@@ -3203,7 +3205,41 @@ extern "C" int sc_local_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm
     SC_REQUIRE(c->g_n == c->e_n, SC_ERR_STATE, "sc_local_moran_seeded: graph missing or size mismatch");
     c->lm_valid = false;
     LmJob j;
-    auto prepare = [&]() -> int { return lm_prepare(c, n_perm, j); };
+    // r04: z, lag and I are final once the preparation has run -- three (cells x genes) float arrays, 1.2 GB at 10^6 cells x
+    // 100 genes, that r03 copied to the caller's (pageable) arrays AFTER the last count, 0.1 s of a 0.5-s call.  A helper
+    // thread un-tiles and copies them out on a stream of its own while the generator and the counts run (neither uses
+    // the PCIe link); this thread keeps enqueuing the pipeline.
+    std::thread copier;
+    int copier_rc = SC_OK;
+    bool copier_started = false;
+    static const bool copy_beside = !getenv("SC_LM_COPY_LATE");   // (A/B)
+    auto prepare = [&]() -> int {
+        SC_TRY(lm_prepare(c, n_perm, j));
+        if (!copy_beside || copier_started) return SC_OK;
+        if (!c->stream_out) SC_HIP(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+        SC_TRY(c->lm_out.ensure(sizeof(float) * (size_t)j.n * (size_t)j.G, &c->mem));
+        hipEvent_t ready;
+        SC_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        SC_HIP(hipEventRecord(ready, c->stream));
+        SC_HIP(hipStreamWaitEvent(c->stream_out, ready, 0));
+        SC_HIP(hipEventDestroy(ready));
+        copier_started = true;
+        const LmJob jj = j;
+        copier = std::thread([c, jj, z_out, lag_out, I_out, &copier_rc]() {
+            if (hipSetDevice(c->device) != hipSuccess) { copier_rc = SC_ERR_HIP; return; }
+            const unsigned gu = (unsigned)ceil_div64(jj.n * jj.G, 256);
+            const struct { const float *src; float *dst; } outs[3] = {{jj.Z32, z_out}, {jj.Lag32, lag_out}, {jj.I32, I_out}};
+            for (const auto &o : outs) {
+                hipLaunchKernelGGL(k_untile<float>, dim3(gu), dim3(256), 0, c->stream_out, o.src, c->lm_out.as<float>(), jj.n, jj.G);
+                if (hipMemcpyAsync(o.dst, c->lm_out.p, sizeof(float) * (size_t)jj.n * (size_t)jj.G, hipMemcpyDeviceToHost, c->stream_out) != hipSuccess ||
+                    hipStreamSynchronize(c->stream_out) != hipSuccess) {   // (the staging buffer is reused by the next array)
+                    copier_rc = SC_ERR_HIP;
+                    return;
+                }
+            }
+        });
+        return SC_OK;
+    };
     auto count = [&](int64_t p0, int64_t p1) -> int {
         if (j.mode == 0) return p1 == n_perm ? lm_count(c, j, 0, 0, n_perm) : SC_OK;   // (the one-kernel form: all rows at the end)
         return lm_count(c, j, 0, p0, p1);
@@ -3212,14 +3248,20 @@ extern "C" int sc_local_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm
     c->pg_ahead = 2;
     int rc = sc_perm_pipeline(c, state6, c->e_n, n_perm, 0, prepare, count);
     if (rc == SC_PERMGEN_RETRY) {   // the block-parallel scan failed its verification: the counts restart at permutation 0
+        if (copier.joinable()) copier.join();   // (the second preparation rewrites what it reads -- with the same values)
         const int mode = c->pg_mode;
         c->pg_mode = 1;
         rc = sc_perm_pipeline(c, state6, c->e_n, n_perm, 0, prepare, count);
         c->pg_mode = mode;
     }
     c->pg_ahead = ahead;
+    if (copier.joinable()) copier.join();
     SC_TRY(rc);
-    return lm_finish(c, j, n_perm, z_out, lag_out, I_out, count_out, zero_var_out);
+    if (copier_started && copier_rc != SC_OK) {
+        sc_set_error("sc_local_moran_seeded: the copy of z / lag / I to the host failed");
+        return copier_rc;
+    }
+    return lm_finish(c, j, n_perm, z_out, lag_out, I_out, count_out, zero_var_out, copier_started);
 }
 
 // hist[gene][c] = cells of the gene with permutation count c (LDS-private per workgroup while 16 genes' worth fits)
