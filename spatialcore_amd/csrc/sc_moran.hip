@@ -2036,8 +2036,13 @@ static int pipe_generate(sc_ctx *c, PermPipe &pp, int64_t k)
     SC_HIP(hipEventCreateWithFlags(&swapped, hipEventDisableTiming));
     SC_TRY(permgen_scan_chunk(c, &pp.job, pp.bounds[(size_t)k + 1], c->stream2, c->stream_px, scanned));
     SC_HIP(hipStreamWaitEvent(sw, scanned, 0));
-    // (two permutations per swap workgroup while the chain still runs: workgroups of the preparation kernels' own size)
-    SC_TRY(permgen_swap_chunk(c, &pp.job, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw, pp.table == 1, k >= chunks - 3 ? 1 : 2));
+    // Two permutations per swap workgroup while the chain still runs -- workgroups of the preparation kernels' own size --
+    // but only beside the Moran scoring kernel (the one consumer that fills its CUs with wavefronts that live for
+    // milliseconds): there the step gains 5 ms (151 against 156).  Two permutations in lockstep take 13-15 ms per chunk
+    // instead of 10-12, and a light consumer (Lee's row sums, the local counts) leaves the chain at 12.8 ms per chunk:
+    // with the pairs the swap stream became the bottleneck (Lee 10 x 10 pairs: 27.8 against 24.9 ms per pair).
+    const int pw = (k < chunks - 3 && c->score_leave_cus > 8) ? 2 : 1;
+    SC_TRY(permgen_swap_chunk(c, &pp.job, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw, pp.table == 1, pw));
     if (pp.table == 2) SC_TRY(invert_rows(c, pp.bounds[(size_t)k], pp.bounds[(size_t)k + 1], sw));
     SC_HIP(hipEventRecord(swapped, sw));
     pp.enqueued = k + 1;
