@@ -178,6 +178,12 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     // fast path: neither a mask change, nor the end of a permutation, nor the end of the job can
     // happen within SCAN_D accepts
     const bool fast = i0 > (mask >> 1) + SCAN_D && c_in + SCAN_D < limit;
+#ifndef SCAN_GAP_FORM
+#define SCAN_GAP_FORM 2      // 1: (shift, xor, min) per draw; 2: two unsigned mins (A/B builds)
+#endif
+#ifndef SCAN_GENERAL_GAP
+#define SCAN_GENERAL_GAP 0   // 1: the general loop tracks the gap for its fast lanes (first step of r04; A/B builds)
+#endif
 #ifdef SCAN_R03_PATHS
     if (fast) {
         uint32_t thr = i0, gap = 0xffffffffu;
@@ -223,8 +229,10 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
     // gap, so a fast lane leaves it with exactly what the fast loop would have given it; and the job's end is looked for
     // only by wavefronts that can reach it.
     if (!__any(!fast)) {
-        uint32_t thr = i0, gap = 0xffffffffu;
+        uint32_t thr = i0;
         bits_t bits = 0;
+#if SCAN_GAP_FORM == 1
+        uint32_t gap = 0xffffffffu;
 #pragma unroll
         for (int s = 0; s < SCAN_D; ++s) {
             const uint32_t v = u[s] & mask;
@@ -234,11 +242,31 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
             bits |= (bits_t)acc << s;
             thr -= acc;
         }
+#else
+        // the slack of an accepted draw is d, of a rejected one -d - 1 = ~d: as UNSIGNED numbers the other one of the pair is
+        // >= 2^31 and never the minimum -- two mins on values the loop has anyway, instead of (shift, xor, min)
+        uint32_t gacc = 0xffffffffu, grej = 0xffffffffu;
+#pragma unroll
+        for (int s = 0; s < SCAN_D; ++s) {
+            const uint32_t v = u[s] & mask;
+            const uint32_t d = thr - v;                  // both < 2^31; accepted iff d < 2^31
+            const uint32_t nd = ~d;
+            const uint32_t acc = nd >> 31;
+            gacc = min(gacc, d);
+            grej = min(grej, nd);
+            bits |= (bits_t)acc << s;
+            thr -= acc;
+        }
+        const uint32_t gap = min(gacc, grej);
+#endif
         r.cnt = i0 - thr; r.bits = bits; r.gap = gap; r.fast = 1;
         return;
     }
     // general path, branch-free: the band / permutation bookkeeping is evaluated for every draw (it is the identity
     // unless the draw was accepted) instead of a divergent branch tree
+    // (r04, second step: no gap in the general loop.  A wavefront comes here because one of its lanes sits at a band edge or
+    // a permutation's end; whatever moves its entering counts moves that edge, and the wavefront is re-evaluated as a whole
+    // anyway -- a validity range for its fast lanes bought nothing in the rounds counter, and costs 3 of 12 operations a draw.)
     uint32_t i = i0, gap = 0xffffffffu;
     bits_t bits = 0;
     if (!__any(!(c_in + SCAN_D < limit))) {   // (wavefront-uniform) the job does not end inside these draws
@@ -251,7 +279,9 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
                 const uint32_t v = u[s] & mask;
                 const int32_t d = (int32_t)(i - v);          // accepted iff d >= 0
                 const uint32_t acc = (uint32_t)(~d) >> 31;
+#if SCAN_GENERAL_GAP
                 gap = min(gap, (uint32_t)(d ^ (d >> 31)));
+#endif
                 bits |= (bits_t)acc << s;
                 i -= acc;
                 const uint32_t half = mask >> 1;
@@ -263,7 +293,9 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
                 const uint32_t v = u[s] & mask;
                 const int32_t d = (int32_t)(i - v);
                 const uint32_t acc = (uint32_t)(~d) >> 31;
+#if SCAN_GENERAL_GAP
                 gap = min(gap, (uint32_t)(d ^ (d >> 31)));
+#endif
                 bits |= (bits_t)acc << s;
                 i -= acc;
                 const bool wrap = i == 0;                 // the permutation is complete: the next one starts at M
@@ -273,7 +305,12 @@ __device__ __forceinline__ void scan_thread(const uint32_t (&u)[SCAN_D], uint32_
             }
         }
         r.cnt = (uint32_t)__popcll((unsigned long long)bits);
+#if SCAN_GENERAL_GAP
         r.bits = bits; r.gap = fast ? gap : 0u; r.fast = fast ? 1u : 0u;
+#else
+        (void)gap;
+        r.bits = bits; r.gap = 0u; r.fast = 0u;
+#endif
         return;
     }
     uint32_t off = c_in, end = 0;
@@ -490,8 +527,9 @@ __device__ __forceinline__ int block_fixed_point(const uint32_t (&u)[SCAN_D], ui
         if (tau == 0) ts->open = (left > (uint64_t)rem_block && rem_block <= SCAN_BLOCK) ? 1u : 0u;
         if (lane == 0) ts->fst[parity][wave] = 0xffffffffu;   // (no front before the first round)
     }
+    uint32_t incl = 0;
     for (int iter = 0;; ++iter) {
-        const uint32_t incl = wave_inclusive_scan(r.cnt);
+        if (recomputed) incl = wave_inclusive_scan(r.cnt);   // (wavefront-uniform: a wavefront that re-evaluated nothing keeps its sums)
         if (lane == 63) sh.wsum[parity][wave] = incl | (recomputed << 31);
 #ifdef PHI_PROFILE
         const long long pf_b0 = clock64();
