@@ -2713,7 +2713,8 @@ int permgen_swap_chunk(sc_ctx *c, PermJob *job, int64_t p0, int64_t p1, hipStrea
     SC_REQUIRE(!inverse || permgen_can_swap_inverse(job->n), SC_ERR_STATE, "permgen_swap_chunk: inverse tables need n >= %d",
                SWAPS_WG_MIN_N);
     KernelTimerScope ts(c, SC_K_PERM_SWAP, s);
-    static const int pw_env = getenv("SC_SWAP_PW") ? atoi(getenv("SC_SWAP_PW")) : 0;   // (development: A/B)
+    const char *pw_e = getenv("SC_SWAP_PW");   // (development and tests: A/B; read per call)
+    const int pw_env = pw_e ? atoi(pw_e) : 0;
     const int pw = pw_env ? pw_env : pw_req;   // permutations per workgroup
     const unsigned wgs = (unsigned)(pw == 2 ? (p1 - p0 + 1) / 2 : p1 - p0);
     // r04 NEGATIVE RESULT, opt-in (SC_SWAP_FULL_ROUNDS=1): whole rounds of 1024 steps (k_apply_swaps_full).  1058 instead of

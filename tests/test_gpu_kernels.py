@@ -378,6 +378,35 @@ def test_moran_seeded_bench_schedule_block_parallel_generator(ctx, oracle):
     assert_counts_match(one["count_ge"][cols], tab)
 
 
+@pytest.mark.parametrize("P", [431, 999])
+def test_moran_pipeline_odd_chunks_with_two_permutations_per_swap_workgroup(ctx, oracle, monkeypatch, P):
+    """Beside the scoring kernel the pipeline's middle chunks are swapped two permutations per workgroup (r04).  P = 431 makes
+    the schedule 32, 103, 128, 96, 48, 24 and P = 999 makes it 32, 31, 128 x 6, ...: chunks with an ODD number of permutations, whose last
+    workgroup has one idle half.  Bit-equal to the one-permutation form (SC_SWAP_PW=1) and to the two-step path on the host
+    generator's table, generator state included."""
+    from spatialcore_amd._lib import perm_numpy_host, rng_state_words
+
+    n, G, k = 140001, 9, 15
+    coords, X = synth(n, G, 21, dtype=np.float32, sparse_x=False)
+    ctx.knn(coords, k, fetch=False)
+    ctx.graph_from_knn(1.0 / k)
+    ctx.set_expression(X, np.arange(G))
+    w2 = rng_state_words(np.random.default_rng(9))
+    two_per_wg = ctx.moran_seeded(w2, P)
+    monkeypatch.setenv("SC_SWAP_PW", "1")
+    w1 = rng_state_words(np.random.default_rng(9))
+    one_per_wg = ctx.moran_seeded(w1, P)
+    monkeypatch.delenv("SC_SWAP_PW")
+    wh = rng_state_words(np.random.default_rng(9))
+    ctx.set_permutations(perm_numpy_host(wh, n, P))
+    two_step = ctx.moran(P)
+    np.testing.assert_array_equal(w2, wh)
+    np.testing.assert_array_equal(w1, wh)
+    for key in ("I", "sims", "count_ge"):
+        np.testing.assert_array_equal(two_per_wg[key], one_per_wg[key], err_msg=key)
+        np.testing.assert_array_equal(two_per_wg[key], two_step[key], err_msg=key)
+
+
 @pytest.mark.parametrize("n,P,cell_p", [(3000, 40, True), (70001, 150, True), (140001, 300, True), (140001, 99, False)])
 def test_lee_local_seeded_equals_the_three_calls(ctx, oracle, n, P, cell_p):
     """sc_lee_local_seeded (the pair body of lees_l_local as one pipeline behind the generator) == sc_perm_generate +
