@@ -178,3 +178,22 @@ def test_swap_rounds_rule_equals_the_sequential_shuffle():
     sim = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sim)
     assert sim.check(seed=11, trials=200) is None
+
+
+def test_fixed_point_rounds_restatement_is_exact():
+    """scripts/fixed_point_rounds_sim.py restates block_fixed_point (sc_permgen.hip) on the CPU to count its rounds; the
+    entering counts it converges to must be those of a plain sequential scan of the block, for a block in which a
+    permutation ends and for an ordinary one, in all three variants it compares."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(__file__), "..", "scripts", "fixed_point_rounds_sim.py")
+    spec = importlib.util.spec_from_file_location("fixed_point_rounds_sim", path)
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    rng = np.random.default_rng(17)
+    for rem in (int(rng.integers(500, 12288)), int(rng.integers(200_000, 900_000))):
+        u = rng.integers(0, 1 << 32, size=(sim.TH, sim.D), dtype=np.int64)
+        want = sim.truth(u, rem)
+        for kw in ({}, {"mode": "newton"}, {"mode": "tail", "tail_i": 1024}):
+            rounds, cnt = sim.run(u, rem, **kw)
+            assert rounds > 0 and np.array_equal(cnt, want), (rem, kw)
