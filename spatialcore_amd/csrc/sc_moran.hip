@@ -3228,9 +3228,9 @@ extern "C" int sc_local_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm
         SC_HIP(hipEventRecord(ready, c->stream));
         SC_HIP(hipStreamWaitEvent(c->stream_out, ready, 0));
         SC_HIP(hipEventDestroy(ready));
-        copier_started = true;
         const LmJob jj = j;
-        copier = std::thread([c, jj, z_out, lag_out, I_out, &copier_rc]() {
+        try {   // (no thread to be had: the arrays are copied at the end, as in r03)
+            copier = std::thread([c, jj, z_out, lag_out, I_out, &copier_rc]() {
             if (hipSetDevice(c->device) != hipSuccess) { copier_rc = SC_ERR_HIP; return; }
             const unsigned gu = (unsigned)ceil_div64(jj.n * jj.G, 256);
             const struct { const float *src; float *dst; } outs[3] = {{jj.Z32, z_out}, {jj.Lag32, lag_out}, {jj.I32, I_out}};
@@ -3242,7 +3242,11 @@ extern "C" int sc_local_moran_seeded(sc_ctx *c, uint64_t *state6, int64_t n_perm
                     return;
                 }
             }
-        });
+            });
+            copier_started = true;
+        } catch (...) {
+            copier_started = false;
+        }
         return SC_OK;
     };
     auto count = [&](int64_t p0, int64_t p1) -> int {
